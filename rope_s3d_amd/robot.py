@@ -1,0 +1,143 @@
+"""Robot geometry as the engine consumes it.
+
+Host-side preparation only (runs once per URDF): welded link meshes concatenated
+into one shared vertex/face buffer (what the reference holds as six pyrender
+meshes, robotpose/simulation/render_utils.py:22-41 — the seventh, link_6_t, is
+dropped there at :31-32), the fixed part of every joint transform (what Klampt
+reads from <origin>/<axis>, kinematics.py:25-27), and the meshlet partition the
+HIP rasteriser walks.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from .constants import NUM_RENDER_LINKS
+from .stl import load_mesh
+from .urdf import URDFReader
+
+MESHLET_MAX_TRIS = 128
+MESHLET_MAX_VERTS = 128
+
+
+def _rpy_matrix(rpy) -> np.ndarray:
+    """URDF fixed-axis roll/pitch/yaw -> R = Rz(yaw)·Ry(pitch)·Rx(roll)."""
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _morton3(q: np.ndarray) -> np.ndarray:
+    """Interleave three 10-bit integer columns into a 30-bit Morton code."""
+    def spread(v):
+        v = v.astype(np.uint64) & 0x3FF
+        v = (v | (v << 16)) & 0x30000FF
+        v = (v | (v << 8)) & 0x300F00F
+        v = (v | (v << 4)) & 0x30C30C3
+        v = (v | (v << 2)) & 0x9249249
+        return v
+    return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+
+
+@dataclass
+class Meshlets:
+    """Spatially compact groups of <=128 triangles over <=128 private vertices.
+
+    header  (M,8) uint32 words: centre x,y,z and radius (float32 bit patterns),
+            first vertex, first triangle, (n_verts | n_tris<<16), link id
+    verts   (Vm,3) float32   meshlet-local vertex copies
+    tris    (Tm,)  uint32    three 8-bit local indices packed i0 | i1<<8 | i2<<16
+    link_first (n_links+1,)  meshlet range of every link
+    """
+    header: np.ndarray
+    verts: np.ndarray
+    tris: np.ndarray
+    link_first: np.ndarray
+
+
+def build_meshlets(link_verts: List[np.ndarray], link_faces: List[np.ndarray]) -> Meshlets:
+    headers, vpool, tpool, link_first = [], [], [], [0]
+    v_base = t_base = 0
+    for link, (V, F) in enumerate(zip(link_verts, link_faces)):
+        cent = V[F].astype(np.float64).mean(axis=1)
+        lo, hi = cent.min(0), cent.max(0)
+        span = np.where(hi > lo, hi - lo, 1.0)
+        code = _morton3(np.minimum(((cent - lo) / span * 1023.0).astype(np.int64), 1023))
+        order = np.argsort(code, kind='stable')
+        Fs = F[order]
+        start = 0
+        nF = len(Fs)
+        while start < nF:
+            # largest prefix of the remaining faces with <=128 tris and <=128 distinct vertices
+            stop = min(start + MESHLET_MAX_TRIS, nF)
+            uniq = np.unique(Fs[start:stop])
+            while len(uniq) > MESHLET_MAX_VERTS:
+                stop -= max(1, (len(uniq) - MESHLET_MAX_VERTS + 1) // 2)
+                uniq = np.unique(Fs[start:stop])
+            local = np.searchsorted(uniq, Fs[start:stop]).astype(np.uint32)
+            pts = V[uniq]
+            p64 = pts.astype(np.float64)
+            c = (p64.min(0) + p64.max(0)) * 0.5
+            rad = float(np.sqrt(((p64 - c) ** 2).sum(1).max())) * (1.0 + 1e-5) + 1e-7
+            hdr = np.zeros(8, np.uint32)
+            hdr[0:4] = np.array([c[0], c[1], c[2], rad], np.float32).view(np.uint32)
+            hdr[4], hdr[5] = v_base, t_base
+            hdr[6] = len(uniq) | ((stop - start) << 16)
+            hdr[7] = link
+            headers.append(hdr)
+            vpool.append(pts)
+            tpool.append(local[:, 0] | (local[:, 1] << 8) | (local[:, 2] << 16))
+            v_base += len(uniq)
+            t_base += stop - start
+            start = stop
+        link_first.append(len(headers))
+    return Meshlets(np.ascontiguousarray(np.stack(headers)),
+                    np.ascontiguousarray(np.concatenate(vpool).astype(np.float32)),
+                    np.ascontiguousarray(np.concatenate(tpool).astype(np.uint32)),
+                    np.array(link_first, np.int32))
+
+
+@dataclass
+class RobotModel:
+    name: str
+    link_names: List[str]
+    joint_limits: np.ndarray            # (6,2)
+    joint_fixed: np.ndarray             # (6,12) row-major 3x4: parent link frame -> joint frame
+    joint_axes: np.ndarray              # (6,3) unit
+    verts: np.ndarray                   # (V,3) float32, links concatenated
+    faces: np.ndarray                   # (T,3) int32, indices local to the link
+    vtx_off: np.ndarray                 # (n_links+1,) int32
+    tri_off: np.ndarray                 # (n_links+1,) int32
+    meshlets: Meshlets = field(repr=False, default=None)
+
+    @property
+    def n_links(self) -> int:
+        return len(self.vtx_off) - 1
+
+    @staticmethod
+    def from_urdf(reader: URDFReader = None, n_links: int = NUM_RENDER_LINKS) -> 'RobotModel':
+        reader = reader or URDFReader()
+        lv, lf = [], []
+        for path in reader.mesh_paths[:n_links]:
+            v, f = load_mesh(path)
+            lv.append(v)
+            lf.append(f)
+        fixed = np.zeros((6, 12))
+        axes = np.zeros((6, 3))
+        for i in range(6):
+            A = np.zeros((3, 4))
+            A[:, :3] = _rpy_matrix(reader.joint_rpy[i]) if np.any(reader.joint_rpy[i]) else np.eye(3)
+            A[:, 3] = reader.joint_origins[i]
+            fixed[i] = A.reshape(-1)
+            a = reader.joint_axes[i]
+            axes[i] = a / np.linalg.norm(a)
+        return RobotModel(
+            name=reader.name, link_names=list(reader.mesh_names[:n_links]),
+            joint_limits=reader.joint_limits.copy(), joint_fixed=fixed, joint_axes=axes,
+            verts=np.ascontiguousarray(np.concatenate(lv)), faces=np.ascontiguousarray(np.concatenate(lf)),
+            vtx_off=np.cumsum([0] + [len(v) for v in lv]).astype(np.int32),
+            tri_off=np.cumsum([0] + [len(f) for f in lf]).astype(np.int32),
+            meshlets=build_meshlets(lv, lf))
