@@ -1,0 +1,112 @@
+/*
+ * rope_s3d.h — C ABI of the MI355X render-and-compare pose engine (librope_hip.so).
+ *
+ * The reference (OSU-AIMS/RoPE-S3D) is pure Python; the calls it makes on this path
+ * go to pyrender/OpenGL, Klampt, TensorFlow and numpy.  Each entry point below names
+ * the reference call site(s) it stands in for.  Conventions: plain pointers and
+ * sizes, caller-owned host buffers, return 0 on success or a negative ROPE_E_* code
+ * (text via rope_last_error), no exceptions cross the boundary, one context per
+ * GPU, a context is not thread-safe (the reference's Predictor is not re-entrant
+ * either: one GL context and mutable target state, predict.py:127-148).
+ */
+#ifndef ROPE_S3D_H
+#define ROPE_S3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rope_ctx rope_ctx;
+
+enum {
+    ROPE_OK = 0,
+    ROPE_E_ARG = -1,      /* bad argument / wrong call order */
+    ROPE_E_HIP = -2,      /* a HIP runtime call failed */
+    ROPE_E_NOMEM = -3
+};
+
+/* Loss kinds (what is reduced over the pixels of one candidate render). */
+enum {
+    ROPE_LOSS_DEPTH = 0,  /* last term of Predictor._error only: mean(D[D!=0])*std(D)   predict.py:503-507 */
+    ROPE_LOSS_FULL = 1,   /* whole Predictor._error                                      predict.py:475-509 */
+    ROPE_LOSS_LOOKUP = 2, /* Lookup stage score mean|T-sqrt(D)|*std over the crop        predict.py:165-171 */
+    ROPE_LOSS_TSWEEP = 3  /* TensorSweep score  mean|sqrt(T)-sqrt(D)| * -std, full frame predict.py:363-369 */
+};
+
+#define ROPE_MAX_LINKS 6          /* link_6_t is never rendered: render_utils.py:31-32 */
+#define ROPE_SUM_WORDS 23         /* uint64 words of integer sums per candidate */
+
+/* Lifetime.  `device` is the HIP device ordinal. */
+int rope_create(rope_ctx **out, int device);
+void rope_destroy(rope_ctx *ctx);
+const char *rope_last_error(rope_ctx *ctx);
+
+/* Robot geometry + kinematic chain, uploaded once.
+ * Replaces MeshLoader.load + pyrender.Mesh.from_trimesh (render_utils.py:22-41) and
+ * klampt.WorldModel(urdf) (kinematics.py:23-33).
+ *   ml_header   n_meshlets x 8 uint32: centre xyz + radius (float bits), first vertex,
+ *               first triangle, n_verts | n_tris<<16, link id
+ *   ml_verts    n_ml_verts x 3 float32 (meshlet-local copies of link-frame vertices)
+ *   ml_tris     n_ml_tris uint32, three 8-bit local indices each
+ *   link_first  n_links+1 meshlet offsets
+ *   joint_fixed 6 x 12 doubles, row-major 3x4 parent-link -> joint frame (<origin>)
+ *   joint_axes  6 x 3 doubles, unit rotation axes (<axis>) */
+int rope_set_robot(rope_ctx *ctx, const uint32_t *ml_header, int n_meshlets, const float *ml_verts,
+                   int n_ml_verts, const uint32_t *ml_tris, int n_ml_tris, const int32_t *link_first,
+                   int n_links, const double *joint_fixed, const double *joint_axes);
+
+/* Camera: PV = P·V (4x4 row-major doubles), image size and clip planes.
+ * Replaces Renderer.setCameraPose (render.py:107-111) + Intrinsics.pyrender_camera
+ * (projection.py:161-169) + pyrender.OffscreenRenderer(W,H) (render.py:60). */
+int rope_set_camera(rope_ctx *ctx, const double *PV, int W, int H, double znear, double zfar);
+
+/* Target of the current frame.
+ * Replaces the cached state of Predictor._load_target/_loadSynthetic (predict.py:397-413,445-469).
+ *   tq         H x W uint64: bits 0..38 target depth in Q32 metres, bits 40..47 link mask bits
+ *   t32        H x W float32 plane for ROPE_LOSS_LOOKUP (lookup target) / ROPE_LOSS_TSWEEP
+ *              (full target); may be NULL when those losses are not used
+ *   link_flags 8 bytes: bit0 link present in the target, bit1 ">5 % of mask has depth" (predict.py:495) */
+int rope_set_target(rope_ctx *ctx, const uint64_t *tq, const float *t32, const uint8_t *link_flags);
+
+/* Candidate joint vectors (C x 6 doubles) into HBM; they stay resident until replaced. */
+int rope_candidates_upload(rope_ctx *ctx, const double *cand, int C);
+
+/* FK + raster of the first n_render links + loss reduction + argmin for the resident
+ * candidates, enqueued on the context's stream (no host sync).
+ * Replaces, per candidate, render_at_pos + _error (predict.py:159-161,475-509) and, for the
+ * lookup loss, the TF reduction over the pre-rendered table (predict.py:167-171).
+ *   crop   r0,r1,c0,c1 inclusive image rows/cols; required for ROPE_LOSS_LOOKUP, else NULL */
+int rope_eval_resident(rope_ctx *ctx, int n_render, int loss, const int32_t *crop);
+
+int rope_sync(rope_ctx *ctx);
+
+/* Results of the last rope_eval_resident.  Any pointer may be NULL.
+ *   err_out  C doubles; sums_out C x ROPE_SUM_WORDS uint64; best_idx/best_err = first argmin */
+int rope_results_download(rope_ctx *ctx, double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err);
+
+/* upload + eval + sync + download in one call (host buffers in, host buffers out). */
+int rope_eval(rope_ctx *ctx, const double *cand, int C, int n_render, int loss, const int32_t *crop,
+              double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err);
+
+/* One pose to images.  Replaces Renderer.setJointAngles + Renderer.render (render.py:88-98).
+ *   depth H x W float32 metres (0 = empty), ids H x W uint8 link id (255 = background) */
+int rope_render(rope_ctx *ctx, const double *q, int n_render, float *depth, uint8_t *ids);
+
+/* OR over candidates of "pixel covered" (H x W uint8 0/1).  Replaces the depth-sum loop
+ * of Crop._create (crop.py:60-81). */
+int rope_coverage(rope_ctx *ctx, const double *cand, int C, int n_render, uint8_t *cover);
+
+/* Device-side per-candidate link matrices of the last eval (C x n_render x 16 float32), for tests. */
+int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);
+
+/* Time `reps` back-to-back rope_eval_resident passes with HIP events on the context's
+ * stream; ms[0] = FK kernel, ms[1] = raster+score kernel, ms[2] = finalize+argmin,
+ * ms[3] = whole pass (averages per pass, milliseconds). */
+int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop, int reps, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

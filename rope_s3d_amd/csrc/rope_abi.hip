@@ -1,0 +1,455 @@
+// rope_abi.hip — host side of librope_hip.so: context, HBM buffers, launch sequencing.
+// Declarations and the reference call sites each entry point replaces: include/rope_s3d.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rope_kernels.h"
+
+using namespace rope;
+
+struct rope_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // robot
+    bool have_robot = false;
+    RobotParams rp{};
+    uint32_t *d_header = nullptr, *d_tris = nullptr;
+    float *d_verts = nullptr;
+    double *d_joint_fixed = nullptr, *d_joint_axes = nullptr;
+    int n_links = 0, n_meshlets = 0;
+
+    // camera
+    bool have_camera = false;
+    FrameParams fp{};
+    double *d_PV = nullptr;
+    int n_tiles = 0;
+
+    // target
+    bool have_target = false;
+    uint64_t *d_tq = nullptr;
+    float *d_t32 = nullptr;
+    bool have_t32 = false;
+    LinkFlags lf{};
+    uint64_t target_version = 0;
+    // per loss: empty-tile sums and their frame total, valid for (target_version, crop)
+    uint64_t *d_empty[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_total[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t empty_version[4] = {0, 0, 0, 0};
+    int empty_crop[4][4] = {};
+
+    // candidates + results
+    int C = 0, cap = 0;
+    double *d_cand = nullptr, *d_err = nullptr, *d_best_err = nullptr;
+    float *d_mvp = nullptr, *d_scale = nullptr;
+    uint64_t *d_sums = nullptr;
+    int32_t *d_best_idx = nullptr;
+    int last_n_render = 0;
+
+    // single-pose render scratch
+    uint32_t *d_key = nullptr;
+    float *d_depth = nullptr;
+    uint8_t *d_ids = nullptr, *d_cover = nullptr;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return ROPE_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define ARG_FAIL(ctx, msg)      \
+    do {                        \
+        (ctx)->err = (msg);     \
+        return ROPE_E_ARG;      \
+    } while (0)
+
+template <typename T>
+static hipError_t realloc_dev(T **p, size_t n)
+{
+    if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+}
+
+static thread_local std::string g_create_err;
+
+extern "C" int rope_create(rope_ctx **out, int device)
+{
+    if (!out) return ROPE_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        g_create_err = "no usable HIP device";
+        return ROPE_E_HIP;
+    }
+    rope_ctx *c = new (std::nothrow) rope_ctx();
+    if (!c) return ROPE_E_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_err = "hipSetDevice/hipStreamCreate failed";
+        delete c;
+        return ROPE_E_HIP;
+    }
+    if (hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void **)&c->d_best_err, sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&c->d_PV, 16 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&c->d_joint_fixed, 72 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&c->d_joint_axes, 18 * sizeof(double)) != hipSuccess) {
+        g_create_err = "hipMalloc failed";
+        delete c;
+        return ROPE_E_NOMEM;
+    }
+    *out = c;
+    return ROPE_OK;
+}
+
+extern "C" void rope_destroy(rope_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_scale, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_depth, c->d_ids, c->d_cover, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
+                    c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *rope_last_error(rope_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_meshlets, const float *ml_verts,
+                              int n_ml_verts, const uint32_t *ml_tris, int n_ml_tris, const int32_t *link_first,
+                              int n_links, const double *joint_fixed, const double *joint_axes)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!ml_header || !ml_verts || !ml_tris || !link_first || !joint_fixed || !joint_axes) ARG_FAIL(c, "rope_set_robot: null pointer");
+    if (n_links < 1 || n_links > ROPE_MAX_LINKS) ARG_FAIL(c, "rope_set_robot: n_links must be 1..6");
+    if (n_meshlets < 1 || n_meshlets > MAX_MESHLETS) ARG_FAIL(c, "rope_set_robot: meshlet count out of range");
+    if (link_first[0] != 0 || link_first[n_links] != n_meshlets) ARG_FAIL(c, "rope_set_robot: link_first does not span the meshlets");
+    // validate every meshlet against the pools so that no kernel can index out of bounds
+    std::vector<double> lo(3 * n_links, 1e30), hi(3 * n_links, -1e30);
+    for (int l = 0; l < n_links; l++) {
+        if (link_first[l + 1] < link_first[l]) ARG_FAIL(c, "rope_set_robot: link_first not monotone");
+        for (int m = link_first[l]; m < link_first[l + 1]; m++) {
+            const uint32_t *h = ml_header + 8 * (size_t)m;
+            uint32_t v0 = h[4], t0 = h[5], nv = h[6] & 0xFFFF, nt = h[6] >> 16;
+            if (h[7] != (uint32_t)l) ARG_FAIL(c, "rope_set_robot: meshlet link id mismatch");
+            if (nv < 1 || nv > MESHLET_MAX_VERTS || (size_t)v0 + nv > (size_t)n_ml_verts) ARG_FAIL(c, "rope_set_robot: meshlet vertex range");
+            if (nt < 1 || (size_t)t0 + nt > (size_t)n_ml_tris) ARG_FAIL(c, "rope_set_robot: meshlet triangle range");
+            for (uint32_t t = 0; t < nt; t++) {
+                uint32_t p = ml_tris[t0 + t];
+                if ((p & 0xFF) >= nv || ((p >> 8) & 0xFF) >= nv || ((p >> 16) & 0xFF) >= nv) ARG_FAIL(c, "rope_set_robot: triangle index outside its meshlet");
+            }
+            for (uint32_t v = 0; v < nv; v++)
+                for (int k = 0; k < 3; k++) {
+                    double x = ml_verts[3 * (size_t)(v0 + v) + k];
+                    if (!std::isfinite(x)) ARG_FAIL(c, "rope_set_robot: non-finite vertex");
+                    lo[3 * l + k] = std::min(lo[3 * l + k], x);
+                    hi[3 * l + k] = std::max(hi[3 * l + k], x);
+                }
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, realloc_dev(&c->d_header, 8 * (size_t)n_meshlets));
+    HIP_TRY(c, realloc_dev(&c->d_verts, 3 * (size_t)n_ml_verts));
+    HIP_TRY(c, realloc_dev(&c->d_tris, (size_t)n_ml_tris));
+    HIP_TRY(c, hipMemcpy(c->d_header, ml_header, 32 * (size_t)n_meshlets, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_verts, ml_verts, 12 * (size_t)n_ml_verts, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tris, ml_tris, 4 * (size_t)n_ml_tris, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_joint_fixed, joint_fixed, 72 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_joint_axes, joint_axes, 18 * sizeof(double), hipMemcpyHostToDevice));
+    c->rp.ml_header = c->d_header;
+    c->rp.ml_verts = c->d_verts;
+    c->rp.ml_tris = c->d_tris;
+    for (int l = 0; l <= ROPE_MAX_LINKS; l++) c->rp.link_first[l] = link_first[l < n_links ? l : n_links];
+    for (int l = 0; l < ROPE_MAX_LINKS; l++) {
+        float *b = c->rp.link_bound + 4 * l;
+        b[0] = b[1] = b[2] = b[3] = 0.0f;
+        if (l >= n_links || link_first[l + 1] == link_first[l]) continue;
+        double cx = 0.5 * (lo[3 * l] + hi[3 * l]), cy = 0.5 * (lo[3 * l + 1] + hi[3 * l + 1]), cz = 0.5 * (lo[3 * l + 2] + hi[3 * l + 2]);
+        double dx = hi[3 * l] - cx, dy = hi[3 * l + 1] - cy, dz = hi[3 * l + 2] - cz;
+        b[0] = (float)cx; b[1] = (float)cy; b[2] = (float)cz;
+        b[3] = (float)(std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001 + 1e-6);
+    }
+    c->n_links = n_links;
+    c->n_meshlets = n_meshlets;
+    c->have_robot = true;
+    return ROPE_OK;
+}
+
+extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, double znear, double zfar)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!PV) ARG_FAIL(c, "rope_set_camera: null PV");
+    if (W < 1 || H < 1 || W > 8192 || H > 8192) ARG_FAIL(c, "rope_set_camera: image size out of range");
+    if (!(znear > 0.0) || !(zfar > znear)) ARG_FAIL(c, "rope_set_camera: need 0 < znear < zfar");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool resized = !c->have_camera || W != c->fp.W || H != c->fp.H;
+    c->fp.W = W; c->fp.H = H;
+    c->fp.tiles_x = (W + TILE_W - 1) / TILE_W;
+    c->fp.tiles_y = (H + TILE_H - 1) / TILE_H;
+    c->fp.r0 = 0; c->fp.r1 = H - 1; c->fp.c0 = 0; c->fp.c1 = W - 1;
+    c->fp.c_num = (float)(2.0 * znear * zfar);
+    c->fp.c_sum = (float)(zfar + znear);
+    c->fp.c_dif = (float)(zfar - znear);
+    c->n_tiles = c->fp.tiles_x * c->fp.tiles_y;
+    HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
+    if (resized) {
+        size_t n = (size_t)W * H;
+        HIP_TRY(c, realloc_dev(&c->d_tq, n));
+        HIP_TRY(c, realloc_dev(&c->d_t32, n));
+        HIP_TRY(c, realloc_dev(&c->d_key, n));
+        HIP_TRY(c, realloc_dev(&c->d_depth, n));
+        HIP_TRY(c, realloc_dev(&c->d_ids, n));
+        HIP_TRY(c, realloc_dev(&c->d_cover, n));
+        for (int k = 0; k < 4; k++) {
+            HIP_TRY(c, realloc_dev(&c->d_empty[k], (size_t)c->n_tiles * ROPE_SUM_WORDS));
+            HIP_TRY(c, realloc_dev(&c->d_total[k], (size_t)ROPE_SUM_WORDS));
+            c->empty_version[k] = 0;
+        }
+        c->have_target = false;
+    }
+    c->have_camera = true;
+    return ROPE_OK;
+}
+
+extern "C" int rope_set_target(rope_ctx *c, const uint64_t *tq, const float *t32, const uint8_t *link_flags)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!c->have_camera) ARG_FAIL(c, "rope_set_target: call rope_set_camera first");
+    if (!tq || !link_flags) ARG_FAIL(c, "rope_set_target: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->fp.W * c->fp.H;
+    HIP_TRY(c, hipMemcpyAsync(c->d_tq, tq, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (t32) HIP_TRY(c, hipMemcpyAsync(c->d_t32, t32, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_t32 = (t32 != nullptr);
+    std::memcpy(c->lf.f, link_flags, 8);
+    c->have_target = true;
+    c->target_version++;
+    return ROPE_OK;
+}
+
+static int ensure_capacity(rope_ctx *c, int C)
+{
+    if (C <= c->cap) return ROPE_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int cap = C < 64 ? 64 : C;
+    HIP_TRY(c, realloc_dev(&c->d_cand, 6 * (size_t)cap));
+    HIP_TRY(c, realloc_dev(&c->d_err, (size_t)cap));
+    HIP_TRY(c, realloc_dev(&c->d_mvp, (size_t)cap * ROPE_MAX_LINKS * 16));
+    HIP_TRY(c, realloc_dev(&c->d_scale, (size_t)cap * ROPE_MAX_LINKS * 4));
+    HIP_TRY(c, realloc_dev(&c->d_sums, (size_t)cap * ROPE_SUM_WORDS));
+    c->cap = cap;
+    return ROPE_OK;
+}
+
+extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!cand || C < 1 || C > 65535) ARG_FAIL(c, "rope_candidates_upload: need 1 <= C <= 65535");
+    for (size_t i = 0; i < 6 * (size_t)C; i++)
+        if (!std::isfinite(cand[i]) || std::fabs(cand[i]) > 1.0e4) ARG_FAIL(c, "rope_candidates_upload: joint angle not finite or |q| > 1e4 rad");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_capacity(c, C);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_cand, cand, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
+    c->C = C;
+    return ROPE_OK;
+}
+
+static int check_eval_args(rope_ctx *c, int n_render, int loss, const int32_t *crop, FrameParams &fp, double &n_pix)
+{
+    if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "eval: robot and camera must be set first");
+    if (c->C < 1) ARG_FAIL(c, "eval: no candidates uploaded");
+    if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "eval: n_render out of range");
+    if (loss < 0 || loss > 3) ARG_FAIL(c, "eval: unknown loss");
+    if (!c->have_target) ARG_FAIL(c, "eval: no target set");
+    if ((loss == ROPE_LOSS_LOOKUP || loss == ROPE_LOSS_TSWEEP) && !c->have_t32) ARG_FAIL(c, "eval: this loss needs the float32 target plane");
+    fp = c->fp;
+    n_pix = (double)fp.W * fp.H;
+    if (loss == ROPE_LOSS_LOOKUP) {
+        if (!crop) ARG_FAIL(c, "eval: lookup loss needs a crop");
+        if (crop[0] < 0 || crop[1] >= fp.H || crop[0] > crop[1] || crop[2] < 0 || crop[3] >= fp.W || crop[2] > crop[3]) ARG_FAIL(c, "eval: crop outside the image");
+        fp.r0 = crop[0]; fp.r1 = crop[1]; fp.c0 = crop[2]; fp.c1 = crop[3];
+        n_pix = (double)(crop[1] - crop[0] + 1) * (double)(crop[3] - crop[2] + 1);
+    }
+    return ROPE_OK;
+}
+
+static int ensure_empty(rope_ctx *c, int loss, const FrameParams &fp)
+{
+    const int cr[4] = {fp.r0, fp.r1, fp.c0, fp.c1};
+    if (c->empty_version[loss] == c->target_version && std::memcmp(cr, c->empty_crop[loss], sizeof cr) == 0) return ROPE_OK;
+    HIP_TRY(c, launch_empty(loss, c->stream, fp, c->d_tq, c->d_t32, c->d_empty[loss], c->d_total[loss]));
+    c->empty_version[loss] = c->target_version;
+    std::memcpy(c->empty_crop[loss], cr, sizeof cr);
+    return ROPE_OK;
+}
+
+static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
+                        hipEvent_t *ev /* 4 events or nullptr */)
+{
+    if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_scale));
+    HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, (size_t)c->C * ROPE_SUM_WORDS * sizeof(uint64_t), c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, n_render, c->d_mvp, c->d_scale, c->d_tq,
+                             c->d_t32, c->d_empty[loss], c->d_sums, nullptr, nullptr));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err,
+                               c->d_best_idx, c->d_best_err));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+    c->last_n_render = n_render;
+    return ROPE_OK;
+}
+
+extern "C" int rope_eval_resident(rope_ctx *c, int n_render, int loss, const int32_t *crop)
+{
+    if (!c) return ROPE_E_ARG;
+    FrameParams fp; double n_pix;
+    int rc = check_eval_args(c, n_render, loss, crop, fp, n_pix);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_empty(c, loss, fp);
+    if (rc) return rc;
+    return enqueue_eval(c, n_render, loss, fp, n_pix, nullptr);
+}
+
+extern "C" int rope_sync(rope_ctx *c)
+{
+    if (!c) return ROPE_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ROPE_OK;
+}
+
+extern "C" int rope_results_download(rope_ctx *c, double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err)
+{
+    if (!c) return ROPE_E_ARG;
+    if (c->C < 1) ARG_FAIL(c, "rope_results_download: nothing evaluated");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (err_out) HIP_TRY(c, hipMemcpyAsync(err_out, c->d_err, (size_t)c->C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (sums_out) HIP_TRY(c, hipMemcpyAsync(sums_out, c->d_sums, (size_t)c->C * ROPE_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (best_idx) HIP_TRY(c, hipMemcpyAsync(best_idx, c->d_best_idx, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (best_err) HIP_TRY(c, hipMemcpyAsync(best_err, c->d_best_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ROPE_OK;
+}
+
+extern "C" int rope_eval(rope_ctx *c, const double *cand, int C, int n_render, int loss, const int32_t *crop,
+                         double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err)
+{
+    int rc = rope_candidates_upload(c, cand, C);
+    if (rc) return rc;
+    rc = rope_eval_resident(c, n_render, loss, crop);
+    if (rc) return rc;
+    return rope_results_download(c, err_out, sums_out, best_idx, best_err);
+}
+
+static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int mode)
+{
+    if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "render: robot and camera must be set first");
+    if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "render: n_render out of range");
+    int rc = rope_candidates_upload(c, cand, C);
+    if (rc) return rc;
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_scale));
+    HIP_TRY(c, launch_raster(mode, ROPE_LOSS_DEPTH, c->C, c->stream, c->fp, c->rp, n_render, c->d_mvp, c->d_scale,
+                             nullptr, nullptr, nullptr, nullptr, c->d_key, c->d_cover));
+    c->last_n_render = n_render;
+    return ROPE_OK;
+}
+
+extern "C" int rope_render(rope_ctx *c, const double *q, int n_render, float *depth, uint8_t *ids)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!q || !depth || !ids) ARG_FAIL(c, "rope_render: null pointer");
+    if (!c->have_camera) ARG_FAIL(c, "rope_render: camera not set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->fp.W * c->fp.H;
+    HIP_TRY(c, hipMemsetAsync(c->d_key, 0xFF, n * sizeof(uint32_t), c->stream));
+    int rc = raster_only(c, q, 1, n_render, MODE_DUMP);
+    if (rc) return rc;
+    HIP_TRY(c, launch_resolve(c->stream, c->d_key, (int)n, c->fp, c->d_depth, c->d_ids));
+    HIP_TRY(c, hipMemcpyAsync(depth, c->d_depth, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ids, c->d_ids, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ROPE_OK;
+}
+
+extern "C" int rope_coverage(rope_ctx *c, const double *cand, int C, int n_render, uint8_t *cover)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!cand || !cover) ARG_FAIL(c, "rope_coverage: null pointer");
+    if (!c->have_camera) ARG_FAIL(c, "rope_coverage: camera not set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->fp.W * c->fp.H;
+    HIP_TRY(c, hipMemsetAsync(c->d_cover, 0, n, c->stream));
+    int rc = raster_only(c, cand, C, n_render, MODE_COVER);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(cover, c->d_cover, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ROPE_OK;
+}
+
+extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!mvp_out || C < 1 || C > c->C || n_render < 1 || n_render > ROPE_MAX_LINKS) ARG_FAIL(c, "rope_debug_mvp: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < C; i++)
+        HIP_TRY(c, hipMemcpy(mvp_out + (size_t)i * n_render * 16, c->d_mvp + (size_t)i * ROPE_MAX_LINKS * 16,
+                             (size_t)n_render * 16 * sizeof(float), hipMemcpyDeviceToHost));
+    return ROPE_OK;
+}
+
+extern "C" int rope_profile_eval(rope_ctx *c, int n_render, int loss, const int32_t *crop, int reps, float *ms)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!ms || reps < 1) ARG_FAIL(c, "rope_profile_eval: bad arguments");
+    FrameParams fp; double n_pix;
+    int rc = check_eval_args(c, n_render, loss, crop, fp, n_pix);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_empty(c, loss, fp);
+    if (rc) return rc;
+    std::vector<hipEvent_t> ev(4 * (size_t)reps);
+    for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
+    for (int r = 0; r < reps; r++) {
+        rc = enqueue_eval(c, n_render, loss, fp, n_pix, &ev[4 * (size_t)r]);
+        if (rc) break;
+    }
+    if (!rc) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        double acc[4] = {0, 0, 0, 0};
+        for (int r = 0; r < reps; r++) {
+            float t;
+            for (int k = 0; k < 3; k++) {
+                HIP_TRY(c, hipEventElapsedTime(&t, ev[4 * (size_t)r + k], ev[4 * (size_t)r + k + 1]));
+                acc[k] += t;
+            }
+        }
+        float total;
+        HIP_TRY(c, hipEventElapsedTime(&total, ev[0], ev[4 * (size_t)reps - 1]));
+        for (int k = 0; k < 3; k++) ms[k] = (float)(acc[k] / reps);
+        ms[3] = total / (float)reps;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}

@@ -1,0 +1,50 @@
+// rope_kernels.h — shared between the kernels (rope_kernels.hip) and the C-ABI host side (rope_abi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rope_s3d.h"
+
+namespace rope {
+
+constexpr int TILE_W = 64;
+constexpr int TILE_H = 64;
+constexpr int MAX_MESHLETS = 4096;        // capacity of the per-tile meshlet list in LDS
+constexpr int MESHLET_MAX_VERTS = 128;
+constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t D24_MAX = 16777215u;
+
+// uint64 words of one candidate's integer sums
+enum { SUM_CNT = 0, SUM_S1 = 1, SUM_AA = 2, SUM_AB = 3, SUM_BB = 4, SUM_LINK0 = 5 };
+static_assert(SUM_LINK0 + 3 * ROPE_MAX_LINKS == ROPE_SUM_WORDS, "sum layout");
+
+enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2 };
+
+struct FrameParams {
+    int W, H, tiles_x, tiles_y;
+    int r0, r1, c0, c1;                   // rows/cols taking part in the loss (whole frame unless lookup crop)
+    float c_num, c_sum, c_dif;            // 2nf, f+n, f-n as float32 (pyrender depth read-back)
+};
+
+struct RobotParams {
+    const uint32_t *ml_header;            // n_meshlets x 8
+    const float *ml_verts;                // x3
+    const uint32_t *ml_tris;
+    int link_first[ROPE_MAX_LINKS + 1];
+    float link_bound[ROPE_MAX_LINKS * 4]; // bounding sphere of every link (link frame)
+};
+
+struct LinkFlags { uint8_t f[8]; };
+
+hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
+                     const double *joint_axes, const double *PV, float *mvp, float *scale);
+hipError_t launch_raster(int mode, int loss, int C, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                         int n_render, const float *mvp, const float *scale, const uint64_t *tq, const float *t32,
+                         const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out, uint8_t *cover);
+hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,
+                        uint64_t *empty_sums, uint64_t *total);
+hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
+                           double n_pix, const LinkFlags &lf, double *err, int32_t *best_idx, double *best_err);
+hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);
+
+}  // namespace rope

@@ -1,0 +1,589 @@
+// rope_kernels.hip — CDNA4 (gfx950) kernels of the render-and-compare pose engine.
+//
+// One pass over a batch of candidate joint vectors is three launches:
+//   fk_mvp_kernel        per candidate: joint angles -> link world transforms -> P·V·M
+//                        (stands in for klampt FK, robotpose/simulation/kinematics.py:36-55,
+//                        and pyrender's node poses, render.py:88-90)
+//   raster_score_kernel  per (candidate, 64x64 screen tile): meshlet culling, vertex shading,
+//                        triangle set-up and z-test into an LDS depth/id tile, then the
+//                        per-pixel loss terms reduced to exact integer sums
+//                        (stands in for pyrender's SEG pass, render.py:92-98, and
+//                        Predictor._error / the lookup reduction, predict.py:475-509,165-171)
+//   finalize_kernel      integer sums -> float64 error, then a wave-shuffle argmin
+//
+// Arithmetic contract: all floating point steps are single IEEE-754
+// operations in the written order (built with -ffp-contract=off; fmaf where fused),
+// pixel reductions are exact integer sums, so results do not depend on the tiling or
+// on the order in which workgroups, waves or atomics complete.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rope_kernels.h"
+
+namespace rope {
+
+// ------------------------------------------------------------------ sincos -----
+// Cody-Waite reduction by pi/2 + msun kernel polynomials, <= 1 ulp of libm.
+__device__ static inline double k_sin(double x, double y)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x, w = z * z;
+    double r = (S2 + z * (S3 + z * S4)) + (z * w) * (S5 + z * S6);
+    double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+__device__ static inline double k_cos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x, w = z * z;
+    double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    double ww = 1.0 - hz;
+    return ww + (((1.0 - ww) - hz) + (z * r - x * y));
+}
+
+__device__ static inline void det_sincos(double x, double &s, double &c)
+{
+    const double PIO2_1 = 1.57079632673412561417e+00, PIO2_1T = 6.07710050650619224932e-11;
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    double fn = rint(x * INV_PIO2);
+    double r = x - fn * PIO2_1;
+    double w = fn * PIO2_1T;
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+    int n = (int)((long long)fn & 3);
+    double sn = k_sin(y0, y1), cs = k_cos(y0, y1);
+    s = (n == 0) ? sn : (n == 1) ? cs : (n == 2) ? -sn : -cs;
+    c = (n == 0) ? cs : (n == 1) ? -sn : (n == 2) ? -cs : sn;
+}
+
+// ------------------------------------------------------------------- FK --------
+__device__ static inline void aff_mul(const double *A, const double *B, double *O)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            O[4 * r + c] = (A[4 * r + 0] * B[0 + c] + A[4 * r + 1] * B[4 + c]) + A[4 * r + 2] * B[8 + c];
+        O[4 * r + 3] = ((A[4 * r + 0] * B[3] + A[4 * r + 1] * B[7]) + A[4 * r + 2] * B[11]) + A[4 * r + 3];
+    }
+}
+
+// One thread per candidate.  Writes n_render 4x4 float matrices plus, per link, the
+// clip-space scale of a unit sphere radius along x, y and w (for meshlet culling).
+__global__ void __launch_bounds__(256)
+fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
+              const double *__restrict__ joint_axes, const double *__restrict__ PV,
+              float *__restrict__ mvp, float *__restrict__ mvp_scale)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int l = 0; l < n_render; l++) {
+        if (l > 0) {
+            int j = l - 1;
+            double s, co;
+            det_sincos(cand[6 * c + j], s, co);
+            double t = 1.0 - co, ax = joint_axes[3 * j], ay = joint_axes[3 * j + 1], az = joint_axes[3 * j + 2];
+            double R[12], A[12], N[12], F[12];
+            R[0] = (t * ax) * ax + co;      R[1] = (t * ax) * ay - s * az;  R[2] = (t * ax) * az + s * ay;  R[3] = 0.0;
+            R[4] = (t * ax) * ay + s * az;  R[5] = (t * ay) * ay + co;      R[6] = (t * ay) * az - s * ax;  R[7] = 0.0;
+            R[8] = (t * ax) * az - s * ay;  R[9] = (t * ay) * az + s * ax;  R[10] = (t * az) * az + co;     R[11] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) F[k] = joint_fixed[12 * j + k];
+            aff_mul(F, R, A);
+            aff_mul(T, A, N);
+#pragma unroll
+            for (int k = 0; k < 12; k++) T[k] = N[k];
+        }
+        float *o = mvp + ((size_t)c * ROPE_MAX_LINKS + l) * 16;
+        float *sc = mvp_scale + ((size_t)c * ROPE_MAX_LINKS + l) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double p0 = PV[4 * r], p1 = PV[4 * r + 1], p2 = PV[4 * r + 2], p3 = PV[4 * r + 3];
+            float m[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                m[k] = (float)((p0 * T[0 + k] + p1 * T[4 + k]) + p2 * T[8 + k]);
+                o[4 * r + k] = m[k];
+            }
+            o[4 * r + 3] = (float)(((p0 * T[3] + p1 * T[7]) + p2 * T[11]) + p3);
+            if (r != 2) {
+                float nrm = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * 1.0001f;
+                sc[r == 3 ? 2 : r] = nrm;
+            }
+        }
+        sc[3] = 0.0f;
+    }
+}
+
+// --------------------------------------------------------------- pixel maths ----
+__device__ static inline float linear_depth(uint32_t d24, float c_num, float c_sum, float c_dif)
+{
+    float d = (float)d24 / 16777215.0f;
+    float t = 2.0f * d - 1.0f;
+    float u = t * c_dif;
+    float den = c_sum - u;
+    return c_num / den;
+}
+
+__device__ static inline uint64_t q32_of_f32(float z) { return (uint64_t)((double)z * 4294967296.0); }
+
+struct Acc {
+    uint64_t w[ROPE_SUM_WORDS];
+};
+
+__device__ static inline void acc_sq(uint64_t *s, uint64_t dq)
+{
+    uint32_t a = (uint32_t)(dq >> 20), b = (uint32_t)(dq & 0xFFFFFu);
+    s[SUM_S1] += dq;
+    s[SUM_AA] += (uint64_t)a * a;
+    s[SUM_AB] += (uint64_t)a * b;
+    s[SUM_BB] += (uint64_t)b * b;
+}
+
+// Loss terms of one pixel given its z-buffer key.  `pix` indexes the H x W target planes.
+template <int LOSS>
+__device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t *__restrict__ tq,
+                                          const float *__restrict__ t32, float c_num, float c_sum, float c_dif,
+                                          uint64_t *s)
+{
+    const bool empty = (key == KEY_EMPTY);
+    float z = empty ? 0.0f : linear_depth(key >> 8, c_num, c_sum, c_dif);
+    if (LOSS == ROPE_LOSS_LOOKUP || LOSS == ROPE_LOSS_TSWEEP) {
+        float a = t32[pix];
+        if (LOSS == ROPE_LOSS_TSWEEP) a = sqrtf(a);
+        float diff = fabsf(a - sqrtf(z));
+        uint64_t dq = q32_of_f32(diff);
+        if (dq) acc_sq(s, dq);
+        return;
+    }
+    const uint64_t t = tq[pix];
+    if (empty && t == 0) return;                  // nothing rendered, no target: every term is zero
+    const uint64_t T = t & 0x7FFFFFFFFFull, zq = q32_of_f32(z);
+    const uint64_t dq = T > zq ? T - zq : zq - T;
+    if (dq) { s[SUM_CNT] += 1; acc_sq(s, dq); }
+    if (LOSS == ROPE_LOSS_FULL) {
+        const unsigned mask = (unsigned)(t >> 40) & 0xFFu;
+        const int id = empty ? 255 : (int)(key & 0xFF);
+#pragma unroll
+        for (int l = 1; l < ROPE_MAX_LINKS; l++) {
+            if (l < n_render) {
+                const bool M = (mask >> l) & 1, R = (id == l);
+                const uint64_t a = M ? T : 0, b = R ? zq : 0;
+                const uint64_t dl = a > b ? a - b : b - a;
+                s[SUM_LINK0 + 3 * l] += (uint64_t)(M != R);
+                if (dl) { s[SUM_LINK0 + 3 * l + 1] += 1; s[SUM_LINK0 + 3 * l + 2] += dl; }
+            }
+        }
+    }
+}
+
+// Pixels of a tile that take part in the loss: inside the image and, for the lookup loss, the crop.
+__device__ static inline bool pixel_active(int row, int col, int W, int H, int r0, int r1, int c0, int c1)
+{
+    return row < H && col < W && row >= r0 && row <= r1 && col >= c0 && col <= c1;
+}
+
+template <int LOSS>
+__device__ static inline void score_tile(const uint32_t *tile /* LDS or nullptr = all empty */, int row0, int col0,
+                                         const FrameParams &fp, int n_render, const uint64_t *__restrict__ tq,
+                                         const float *__restrict__ t32, uint64_t *lds_sums)
+{
+    uint64_t s[ROPE_SUM_WORDS];
+#pragma unroll
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
+    for (int i = threadIdx.x; i < TILE_W * TILE_H; i += blockDim.x) {
+        int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
+        if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
+        uint32_t key = tile ? tile[i] : KEY_EMPTY;
+        score_pixel<LOSS>(key, (size_t)row * fp.W + col, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+    }
+#pragma unroll
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) {
+        const bool used = (LOSS == ROPE_LOSS_FULL) ? true : (k < SUM_LINK0);
+        if (used && s[k]) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)s[k]);
+    }
+}
+
+// Sums of every tile when nothing is rendered into it; the raster kernel adds
+// (actual - empty) for the tiles it touches, finalize adds the frame total back.
+template <int LOSS>
+__global__ void __launch_bounds__(256)
+empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *__restrict__ t32,
+                  uint64_t *__restrict__ empty_sums /* n_tiles x SUM_WORDS */)
+{
+    __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
+    if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
+    __syncthreads();
+    int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
+    score_tile<LOSS>(nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, lds_sums);
+    __syncthreads();
+    if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
+}
+
+__global__ void total_tiles_kernel(const uint64_t *__restrict__ empty_sums, int n_tiles, uint64_t *__restrict__ total)
+{
+    int k = threadIdx.x;
+    if (k >= ROPE_SUM_WORDS) return;
+    uint64_t t = 0;
+    for (int i = 0; i < n_tiles; i++) t += empty_sums[(size_t)i * ROPE_SUM_WORDS + k];
+    total[k] = t;
+}
+
+// ------------------------------------------------------------------ raster -----
+struct SVert { int32_t X, Y; float d; };
+#define SV_BAD INT32_MIN
+
+__device__ static inline SVert shade_vertex(const float *m, float x, float y, float z, float hw, float hh)
+{
+    float cx = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
+    float cy = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
+    float cz = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11])));
+    float cw = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15])));
+    bool ok = (cw > 0.0f) && (cz >= -cw) && (cz <= cw);
+    float rw = 1.0f / cw;
+    float sx = fmaf(cx * rw, hw, hw);
+    float sy = fmaf(cy * rw, hh, hh);
+    SVert o;
+    o.d = fmaf(cz * rw, 0.5f, 0.5f);
+    ok = ok && (fabsf(sx) < 1.0e6f) && (fabsf(sy) < 1.0e6f);
+    o.X = ok ? (int32_t)rintf(sx * 256.0f) : SV_BAD;
+    o.Y = ok ? (int32_t)rintf(sy * 256.0f) : 0;
+    return o;
+}
+
+__device__ static inline bool owns(int32_t ax, int32_t ay, int32_t bx, int32_t by)
+{
+    int32_t dy = by - ay, dx = bx - ax;
+    return (dy < 0) || (dy == 0 && dx < 0);
+}
+
+__device__ static inline int64_t edge_fn(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t fx, int32_t fy)
+{
+    return (int64_t)(bx - ax) * (int64_t)(fy - ay) - (int64_t)(by - ay) * (int64_t)(fx - ax);
+}
+
+// Conservative screen-space test of a bounding sphere against a pixel rectangle
+// [px0,px1] x [py0,py1] (GL window coordinates, y up).  Only ever answers "no" when no
+// sample of the rectangle can be covered; it never changes results, only work.
+__device__ static inline bool sphere_hits_rect(const float *m, const float *sc, float x, float y, float z, float rad,
+                                               float hw, float hh, float px0, float px1, float py0, float py1)
+{
+    float cx = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
+    float cy = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
+    float cw = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15])));
+    float rx = rad * sc[0], ry = rad * sc[1], rw = rad * sc[2];
+    float wlo = cw - rw, whi = cw + rw;
+    if (whi <= 0.0f) return false;                 // wholly behind the eye: every vertex has w <= 0
+    if (wlo <= 1e-6f) return true;                 // straddles the eye plane: cannot bound
+    float ilo = 1.0f / wlo, ihi = 1.0f / whi;
+    float xlo = cx - rx, xhi = cx + rx, ylo = cy - ry, yhi = cy + ry;
+    float nxlo = xlo < 0.0f ? xlo * ilo : xlo * ihi, nxhi = xhi > 0.0f ? xhi * ilo : xhi * ihi;
+    float nylo = ylo < 0.0f ? ylo * ilo : ylo * ihi, nyhi = yhi > 0.0f ? yhi * ilo : yhi * ihi;
+    float sxlo = fmaf(nxlo, hw, hw) - 1.5f, sxhi = fmaf(nxhi, hw, hw) + 1.5f;
+    float sylo = fmaf(nylo, hh, hh) - 1.5f, syhi = fmaf(nyhi, hh, hh) + 1.5f;
+    return !(sxhi < px0 || sxlo > px1 + 1.0f || syhi < py0 || sylo > py1 + 1.0f);
+}
+
+// MODE_SCORE: reduce the loss and add (actual - empty) into the candidate's sums.
+// MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
+// MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
+template <int LOSS, int MODE>
+__global__ void __launch_bounds__(256)
+raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *__restrict__ mvp_all,
+                    const float *__restrict__ scale_all, const uint64_t *__restrict__ tq,
+                    const float *__restrict__ t32, const uint64_t *__restrict__ empty_sums,
+                    uint64_t *__restrict__ sums, uint32_t *__restrict__ key_out, uint8_t *__restrict__ cover)
+{
+    __shared__ uint32_t tile[TILE_W * TILE_H];
+    __shared__ float s_mvp[ROPE_MAX_LINKS * 16];
+    __shared__ float s_scale[ROPE_MAX_LINKS * 4];
+    __shared__ uint16_t s_list[MAX_MESHLETS];
+    __shared__ int s_count;
+    __shared__ SVert s_vert[4][MESHLET_MAX_VERTS];
+    __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile_id = blockIdx.x, cand = blockIdx.y;
+    const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
+    const int col0 = tx * TILE_W, row0 = ty * TILE_H;
+    // tile rectangle in GL window pixel coordinates (y up), clamped to the image
+    const int wx0 = col0, wx1 = min(col0 + TILE_W, fp.W) - 1;
+    const int wy1 = fp.H - 1 - row0, wy0 = max(fp.H - row0 - TILE_H, 0);
+    const float hw = 0.5f * (float)fp.W, hh = 0.5f * (float)fp.H;
+
+    if (tid < n_render * 16) s_mvp[tid] = mvp_all[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
+    if (tid < n_render * 4) s_scale[tid] = scale_all[((size_t)cand * ROPE_MAX_LINKS) * 4 + tid];
+    if (tid == 0) s_count = 0;
+    if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
+    __syncthreads();
+
+    // --- meshlet culling: links first (6 spheres), then the meshlets of the links that hit
+    unsigned link_hit = 0;
+    for (int l = 0; l < n_render; l++) {
+        const float *b = rp.link_bound + 4 * l;
+        if (sphere_hits_rect(s_mvp + 16 * l, s_scale + 4 * l, b[0], b[1], b[2], b[3], hw, hh,
+                             (float)wx0, (float)wx1, (float)wy0, (float)wy1))
+            link_hit |= 1u << l;
+    }
+    if (link_hit) {
+        const int m_end = rp.link_first[n_render];
+        for (int m = tid; m < m_end; m += blockDim.x) {
+            const uint4 h0 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m];
+            const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
+            const int l = (int)h1.w;
+            if (!((link_hit >> l) & 1)) continue;
+            if (sphere_hits_rect(s_mvp + 16 * l, s_scale + 4 * l, __uint_as_float(h0.x), __uint_as_float(h0.y),
+                                 __uint_as_float(h0.z), __uint_as_float(h0.w), hw, hh, (float)wx0, (float)wx1,
+                                 (float)wy0, (float)wy1)) {
+                int pos = atomicAdd(&s_count, 1);
+                s_list[pos] = (uint16_t)m;
+            }
+        }
+    }
+    for (int i = tid; i < TILE_W * TILE_H; i += blockDim.x) tile[i] = KEY_EMPTY;
+    __syncthreads();
+    const int n_list = s_count;
+    if (n_list == 0) return;                      // nothing can land in this tile: its sums stay "empty"
+
+    // --- one meshlet per wave at a time
+    for (int li = wave; li < n_list; li += 4) {
+        const int m = s_list[li];
+        const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
+        const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16), l = (int)h1.w;
+        const float *mm = s_mvp + 16 * l;
+        for (int v = lane; v < nv; v += 64) {
+            const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
+            s_vert[wave][v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int t = lane; t < nt; t += 64) {
+            const uint32_t packed = rp.ml_tris[t0 + t];
+            const SVert a = s_vert[wave][packed & 0xFF], b = s_vert[wave][(packed >> 8) & 0xFF],
+                        c = s_vert[wave][(packed >> 16) & 0xFF];
+            if (a.X == SV_BAD || b.X == SV_BAD || c.X == SV_BAD) continue;
+            const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
+            if (area2 <= 0) continue;             // back-facing or degenerate
+            const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
+            const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
+            const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
+            const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
+            if (x0 > x1 || y0 > y1) continue;     // no sample centre inside the bounding box
+            const int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1;
+            const int64_t b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1;
+            const int64_t b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
+            const double inv = 1.0 / (double)area2;
+            const double d0 = (double)a.d, e1 = (double)b.d - (double)a.d, e2 = (double)c.d - (double)a.d;
+            // per-pixel x step of each edge function
+            const int64_t s01 = -(int64_t)(b.Y - a.Y) * 256, s12 = -(int64_t)(c.Y - b.Y) * 256, s20 = -(int64_t)(a.Y - c.Y) * 256;
+            for (int py = y0; py <= y1; py++) {
+                const int32_t fy = py * 256 + 128, fx0 = x0 * 256 + 128;
+                int64_t E01 = edge_fn(a.X, a.Y, b.X, b.Y, fx0, fy);
+                int64_t E12 = edge_fn(b.X, b.Y, c.X, c.Y, fx0, fy);
+                int64_t E20 = edge_fn(c.X, c.Y, a.X, a.Y, fx0, fy);
+                uint32_t *trow = tile + (fp.H - 1 - py - row0) * TILE_W - col0;
+                for (int px = x0; px <= x1; px++, E01 += s01, E12 += s12, E20 += s20) {
+                    if (((E01 + b01) | (E12 + b12) | (E20 + b20)) < 0) continue;
+                    const double l1 = (double)E20 * inv, l2 = (double)E01 * inv;
+                    const double dd = d0 + (l1 * e1 + l2 * e2);
+                    const double qd = dd * 16777215.0 + 0.5;
+                    const uint32_t d24 = qd < 0.0 ? 0u : (qd >= 16777215.0 ? D24_MAX : (uint32_t)qd);
+                    if (d24 >= D24_MAX) continue; // GL_LESS against the cleared depth of 1.0
+                    atomicMin(&trow[px], (d24 << 8) | (uint32_t)l);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    if (MODE == MODE_DUMP) {
+        for (int i = tid; i < TILE_W * TILE_H; i += blockDim.x) {
+            int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
+            if (row < fp.H && col < fp.W) key_out[(size_t)row * fp.W + col] = tile[i];
+        }
+        return;
+    }
+    if (MODE == MODE_COVER) {
+        for (int i = tid; i < TILE_W * TILE_H; i += blockDim.x) {
+            int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
+            if (row < fp.H && col < fp.W && tile[i] != KEY_EMPTY) cover[(size_t)row * fp.W + col] = 1;
+        }
+        return;
+    }
+    score_tile<LOSS>(tile, row0, col0, fp, n_render, tq, t32, lds_sums);
+    __syncthreads();
+    if (tid < ROPE_SUM_WORDS) {
+        const uint64_t delta = lds_sums[tid] - empty_sums[(size_t)tile_id * ROPE_SUM_WORDS + tid];
+        if (delta) atomicAdd((unsigned long long *)&sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
+    }
+}
+
+// ---------------------------------------------------------------- finalize -----
+__device__ static inline double mean_std_parts(const uint64_t *s, double N, double &m1)
+{
+    m1 = ((double)s[SUM_S1] * 0x1p-32) / N;
+    double S2 = ((double)s[SUM_AA] * 0x1p40 + (double)s[SUM_AB] * 0x1p21) + (double)s[SUM_BB];
+    double m2 = (S2 * 0x1p-64) / N;
+    double var = m2 - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    return sqrt(var);
+}
+
+__global__ void __launch_bounds__(256)
+finalize_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_empty, int C, int loss,
+                int n_render, double n_pix, LinkFlags lf, double *__restrict__ err)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    uint64_t s[ROPE_SUM_WORDS];
+#pragma unroll
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) {
+        // words of links that were not rendered (or of a loss without link terms) read as zero
+        const bool live = k < SUM_LINK0 || (loss == ROPE_LOSS_FULL && k < SUM_LINK0 + 3 * n_render);
+        s[k] = live ? sums[(size_t)c * ROPE_SUM_WORDS + k] + total_empty[k] : 0;
+        sums[(size_t)c * ROPE_SUM_WORDS + k] = s[k];
+    }
+    double m1, sd = mean_std_parts(s, n_pix, m1);
+    double e;
+    if (loss == ROPE_LOSS_LOOKUP) e = m1 * sd;
+    else if (loss == ROPE_LOSS_TSWEEP) e = m1 * -sd;
+    else {
+        e = 0.0;
+        if (loss == ROPE_LOSS_FULL)
+            for (int l = 1; l < n_render; l++) {
+                if (!(lf.f[l] & 1)) continue;
+                e += ((double)s[SUM_LINK0 + 3 * l] / n_pix) * 5.0;
+                if ((lf.f[l] & 2) && s[SUM_LINK0 + 3 * l + 1] > 0)
+                    e += (((double)s[SUM_LINK0 + 3 * l + 2] * 0x1p-32) / (double)s[SUM_LINK0 + 3 * l + 1]) * 10.0;
+            }
+        double meanD = ((double)s[SUM_S1] * 0x1p-32) / (double)s[SUM_CNT];
+        e += meanD * sd;
+    }
+    err[c] = e;
+}
+
+// First index of the smallest error (NaN never wins against a number).  One block.
+__global__ void __launch_bounds__(1024)
+argmin_kernel(const double *__restrict__ err, int C, int32_t *__restrict__ best_idx, double *__restrict__ best_err)
+{
+    __shared__ double s_e[16];
+    __shared__ int s_i[16];
+    double be = __builtin_inf();
+    int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        double e = err[i];
+        if (e < be || (e == be && i < bi) || (bi == 0x7FFFFFFF && !(e != e))) { be = e; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double oe = __shfl_xor(be, off, 64);
+        int oi = __shfl_xor(bi, off, 64);
+        if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_e[wave] = be; s_i[wave] = bi; }
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = blockDim.x >> 6;
+        be = lane < nw ? s_e[lane] : __builtin_inf();
+        bi = lane < nw ? s_i[lane] : 0x7FFFFFFF;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            double oe = __shfl_xor(be, off, 64);
+            int oi = __shfl_xor(bi, off, 64);
+            if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
+        }
+        if (lane == 0) { *best_idx = (bi == 0x7FFFFFFF) ? 0 : bi; *best_err = (bi == 0x7FFFFFFF) ? err[0] : be; }
+    }
+}
+
+// key image -> metric depth + link id (single-pose render path)
+__global__ void resolve_kernel(const uint32_t *__restrict__ key, int n, float c_num, float c_sum, float c_dif,
+                               float *__restrict__ depth, uint8_t *__restrict__ ids)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = key[i];
+    depth[i] = (k == KEY_EMPTY) ? 0.0f : linear_depth(k >> 8, c_num, c_sum, c_dif);
+    ids[i] = (k == KEY_EMPTY) ? 255 : (uint8_t)(k & 0xFF);
+}
+
+// ------------------------------------------------------------ launch helpers ---
+template <int MODE>
+static hipError_t launch_raster_mode(int loss, dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                                     int n_render, const float *mvp, const float *scale, const uint64_t *tq,
+                                     const float *t32, const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out,
+                                     uint8_t *cover)
+{
+    switch (loss) {
+    case ROPE_LOSS_DEPTH:
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_DEPTH, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        break;
+    case ROPE_LOSS_FULL:
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_FULL, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        break;
+    case ROPE_LOSS_LOOKUP:
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_LOOKUP, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        break;
+    default:
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_TSWEEP, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
+                     const double *joint_axes, const double *PV, float *mvp, float *scale)
+{
+    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, mvp, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster(int mode, int loss, int C, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                         int n_render, const float *mvp, const float *scale, const uint64_t *tq, const float *t32,
+                         const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out, uint8_t *cover)
+{
+    dim3 grid(fp.tiles_x * fp.tiles_y, C);
+    if (mode == MODE_DUMP) return launch_raster_mode<MODE_DUMP>(ROPE_LOSS_DEPTH, grid, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+    if (mode == MODE_COVER) return launch_raster_mode<MODE_COVER>(ROPE_LOSS_DEPTH, grid, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+    return launch_raster_mode<MODE_SCORE>(loss, grid, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+}
+
+hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,
+                        uint64_t *empty_sums, uint64_t *total)
+{
+    dim3 grid(fp.tiles_x * fp.tiles_y);
+    switch (loss) {
+    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
+    case ROPE_LOSS_FULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_FULL>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
+    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_LOOKUP>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
+    default: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
+    }
+    hipLaunchKernelGGL(total_tiles_kernel, dim3(1), dim3(64), 0, st, empty_sums, fp.tiles_x * fp.tiles_y, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
+                           double n_pix, const LinkFlags &lf, double *err, int32_t *best_idx, double *best_err)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, total_empty, C, loss, n_render, n_pix, lf, err);
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, st, err, C, best_idx, best_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids)
+{
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, st, key, n, fp.c_num, fp.c_sum, fp.c_dif, depth, ids);
+    return hipGetLastError();
+}
+
+}  // namespace rope

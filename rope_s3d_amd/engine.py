@@ -1,0 +1,205 @@
+"""ctypes binding of the HIP engine (librope_hip.so, ABI in include/rope_s3d.h).
+
+This module is the only way the Python host code reaches the GPU.  There is no CPU
+fallback: if the shared library is missing or no HIP device is usable, construction
+raises `EngineUnavailable`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+from .robot import RobotModel
+
+LOSS_DEPTH, LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP = 0, 1, 2, 3
+SUM_WORDS = 23
+Q32 = 4294967296.0
+TQ_MAX = (1 << 39) - 1
+
+ABI_SYMBOLS = (
+    'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
+    'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
+    'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval')
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = None):
+    """dlopen librope_hip.so and declare the prototypes.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get('ROPE_HIP_LIB', LIB_PATH)
+    if not os.path.exists(path):
+        raise EngineUnavailable(f"{path} not found: build it with `python -m rope_s3d_amd.build` "
+                                "(hipcc, gfx950); the engine has no CPU fallback")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise EngineUnavailable(f"cannot load {path}: {e}") from e
+    vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+    lib.rope_create.argtypes = [C.POINTER(vp), i32]
+    lib.rope_destroy.argtypes = [vp]
+    lib.rope_destroy.restype = None
+    lib.rope_last_error.argtypes = [vp]
+    lib.rope_last_error.restype = C.c_char_p
+    lib.rope_set_robot.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp]
+    lib.rope_set_camera.argtypes = [vp, vp, i32, i32, dbl, dbl]
+    lib.rope_set_target.argtypes = [vp, vp, vp, vp]
+    lib.rope_candidates_upload.argtypes = [vp, vp, i32]
+    lib.rope_eval_resident.argtypes = [vp, i32, i32, vp]
+    lib.rope_sync.argtypes = [vp]
+    lib.rope_results_download.argtypes = [vp, vp, vp, vp, vp]
+    lib.rope_eval.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.rope_render.argtypes = [vp, vp, i32, vp, vp]
+    lib.rope_coverage.argtypes = [vp, vp, i32, i32, vp]
+    lib.rope_debug_mvp.argtypes = [vp, vp, i32, i32]
+    lib.rope_profile_eval.argtypes = [vp, i32, i32, vp, i32, vp]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def pack_target(depth: np.ndarray, mask_bits: np.ndarray = None) -> np.ndarray:
+    """Target depth (metres) + per-link mask bits -> the uint64 plane rope_set_target takes.
+
+    bits 0..38: depth in Q32 metres (round half even, clipped to [0, 2^39-1]; NaN and
+    negatives count as "no depth" = 0); bits 40..47: bit l set where link l's mask is true.
+    """
+    d = np.asarray(depth, np.float64)
+    q = np.rint(np.where(np.isfinite(d) & (d > 0), d, 0.0) * Q32)
+    q = np.minimum(q, float(TQ_MAX)).astype(np.uint64)
+    if mask_bits is not None:
+        q |= np.asarray(mask_bits, np.uint64) << np.uint64(40)
+    return np.ascontiguousarray(q)
+
+
+class Engine:
+    """One engine context on one GPU: robot + camera + current target, batched evaluation."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.rope_create(C.byref(self._ctx), int(device))
+        if rc != 0:
+            msg = self._lib.rope_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise EngineUnavailable(f"rope_create(device={device}) failed ({rc}): {msg}")
+        self.device = device
+        self.W = self.H = 0
+        self.n_links = 0
+        self.n_candidates = 0
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            self._lib.rope_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self._lib.rope_last_error(self._ctx).decode()}")
+
+    # -- static state -------------------------------------------------------------------------
+    def set_robot(self, robot: RobotModel):
+        m = robot.meshlets
+        hdr = np.ascontiguousarray(m.header, np.uint32)
+        verts = np.ascontiguousarray(m.verts, np.float32)
+        tris = np.ascontiguousarray(m.tris, np.uint32)
+        first = np.ascontiguousarray(m.link_first, np.int32)
+        jf = np.ascontiguousarray(robot.joint_fixed, np.float64)
+        ja = np.ascontiguousarray(robot.joint_axes, np.float64)
+        self._check(self._lib.rope_set_robot(self._ctx, _p(hdr), len(hdr), _p(verts), len(verts), _p(tris), len(tris),
+                                             _p(first), len(first) - 1, _p(jf), _p(ja)), 'rope_set_robot')
+        self.n_links = len(first) - 1
+
+    def set_camera(self, PV: np.ndarray, W: int, H: int, znear: float, zfar: float):
+        PV = np.ascontiguousarray(PV, np.float64)
+        assert PV.shape == (4, 4)
+        self._check(self._lib.rope_set_camera(self._ctx, _p(PV), int(W), int(H), float(znear), float(zfar)), 'rope_set_camera')
+        self.W, self.H = int(W), int(H)
+
+    def set_target(self, tq: np.ndarray, t32: np.ndarray = None, link_flags=None):
+        tq = np.ascontiguousarray(tq, np.uint64)
+        if tq.shape != (self.H, self.W):
+            raise ValueError(f"target plane must be {(self.H, self.W)}, got {tq.shape}")
+        if t32 is not None:
+            t32 = np.ascontiguousarray(t32, np.float32)
+            if t32.shape != (self.H, self.W):
+                raise ValueError("float32 target plane has the wrong shape")
+        lf = np.zeros(8, np.uint8)
+        if link_flags is not None:
+            lf[:len(link_flags)] = link_flags
+        self._check(self._lib.rope_set_target(self._ctx, _p(tq), _p(t32), _p(lf)), 'rope_set_target')
+
+    # -- evaluation ---------------------------------------------------------------------------
+    def upload_candidates(self, cand: np.ndarray):
+        cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
+        self._check(self._lib.rope_candidates_upload(self._ctx, _p(cand), len(cand)), 'rope_candidates_upload')
+        self.n_candidates = len(cand)
+
+    def eval_resident(self, n_render: int, loss: int, crop=None):
+        crop_a = np.ascontiguousarray(crop, np.int32) if crop is not None else None
+        self._check(self._lib.rope_eval_resident(self._ctx, int(n_render), int(loss), _p(crop_a)), 'rope_eval_resident')
+
+    def sync(self):
+        self._check(self._lib.rope_sync(self._ctx), 'rope_sync')
+
+    def download(self, want_err=True, want_sums=False):
+        n = self.n_candidates
+        err = np.empty(n, np.float64) if want_err else None
+        sums = np.empty((n, SUM_WORDS), np.uint64) if want_sums else None
+        bi, be = C.c_int32(), C.c_double()
+        self._check(self._lib.rope_results_download(self._ctx, _p(err), _p(sums), C.byref(bi), C.byref(be)), 'rope_results_download')
+        return err, sums, int(bi.value), float(be.value)
+
+    def eval(self, cand, n_render: int, loss: int, crop=None, want_sums=False):
+        """-> (err (C,), sums or None, first-argmin index, its error)."""
+        self.upload_candidates(cand)
+        self.eval_resident(n_render, loss, crop)
+        return self.download(True, want_sums)
+
+    def render(self, q, n_render: int = 6):
+        """-> (depth float32 HxW metres, link id uint8 HxW with 255 = background)."""
+        q = np.ascontiguousarray(q, np.float64).reshape(6)
+        depth = np.empty((self.H, self.W), np.float32)
+        ids = np.empty((self.H, self.W), np.uint8)
+        self._check(self._lib.rope_render(self._ctx, _p(q), int(n_render), _p(depth), _p(ids)), 'rope_render')
+        return depth, ids
+
+    def coverage(self, cand, n_render: int) -> np.ndarray:
+        cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
+        cover = np.empty((self.H, self.W), np.uint8)
+        self._check(self._lib.rope_coverage(self._ctx, _p(cand), len(cand), int(n_render), _p(cover)), 'rope_coverage')
+        self.n_candidates = len(cand)
+        return cover
+
+    def debug_mvp(self, C_: int, n_render: int) -> np.ndarray:
+        out = np.empty((C_, n_render, 16), np.float32)
+        self._check(self._lib.rope_debug_mvp(self._ctx, _p(out), int(C_), int(n_render)), 'rope_debug_mvp')
+        return out
+
+    def profile_eval(self, n_render: int, loss: int, crop=None, reps: int = 10):
+        """-> dict of average milliseconds per pass: fk, raster, finalize, total (HIP events on the engine stream)."""
+        crop_a = np.ascontiguousarray(crop, np.int32) if crop is not None else None
+        ms = np.zeros(4, np.float32)
+        self._check(self._lib.rope_profile_eval(self._ctx, int(n_render), int(loss), _p(crop_a), int(reps), _p(ms)), 'rope_profile_eval')
+        return {'fk': float(ms[0]), 'raster': float(ms[1]), 'finalize': float(ms[2]), 'total': float(ms[3])}

@@ -1,0 +1,72 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from rope_s3d_amd import engine as eng
+from rope_s3d_amd.constants import ZFAR, ZNEAR
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+POSES = [
+    [0, 0, 0, 0, 0, 0],
+    [0.3, 0.4, 0.5, 0, 0, 0],
+    [-0.7, -0.9, 2.2, 0, 0, 0],
+    [1.5, 1.2, -0.8, 0.5, -0.7, 0.3],
+    [0.8, 0.1, 1.0, -2.0, 1.5, 3.0],
+]
+
+
+@pytest.fixture(scope='module')
+def scene():
+    rb = helpers.robot()
+    intr, PV = helpers.camera('640_480_color')
+    o = helpers.make_oracle(rb, intr, PV)
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+    return rb, intr, PV, o, e
+
+
+def test_link_matrices_bit_exact(scene):
+    rb, intr, PV, o, e = scene
+    cand = np.array(POSES, np.float64)
+    d, ids = o.render(POSES[1])
+    tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+    e.set_target(tq, t32, flags)
+    e.eval(cand, 6, eng.LOSS_DEPTH)
+    got = e.debug_mvp(len(cand), 6)
+    for i, q in enumerate(POSES):
+        want = o.mvp(q, 6)
+        assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), f"pose {i}"
+
+
+@pytest.mark.parametrize('n_render', [4, 6])
+def test_render_bit_exact(scene, n_render):
+    rb, intr, PV, o, e = scene
+    for q in POSES:
+        d_ref, id_ref = o.render(q, n_render)
+        d, ids = e.render(q, n_render)
+        assert np.array_equal(ids, id_ref), f"segment ids differ at {q}: {(ids != id_ref).sum()} px"
+        assert np.array_equal(d.view(np.uint32), d_ref.view(np.uint32)), f"depth differs at {q}"
+
+
+@pytest.mark.parametrize('loss,n_render', [(eng.LOSS_DEPTH, 6), (eng.LOSS_FULL, 6), (eng.LOSS_FULL, 4),
+                                           (eng.LOSS_LOOKUP, 6), (eng.LOSS_TSWEEP, 6)])
+def test_eval_sums_and_errors_bit_exact(scene, loss, n_render):
+    rb, intr, PV, o, e = scene
+    d, ids = o.render([0.35, 0.45, 0.9, 0, 0, 0])
+    tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+    if loss == eng.LOSS_TSWEEP:
+        t32 = d.copy()
+    e.set_target(tq, t32, flags)
+    cand = helpers.slu_grid(rb.joint_limits, 4)
+    crop = [150, 479, 200, 600] if loss == eng.LOSS_LOOKUP else None
+    err_ref, sums_ref = o.eval(cand, loss, n_render, tq, t32, crop, flags, threads=8, want_sums=True)
+    err, sums, bi, be = e.eval(cand, n_render, loss, crop, want_sums=True)
+    used = 23 if loss == eng.LOSS_FULL else 5
+    assert np.array_equal(sums[:, :used], sums_ref[:, :used])
+    assert np.array_equal(err.view(np.uint64), err_ref.view(np.uint64))
+    assert bi == int(np.argmin(err_ref)) and be == err_ref[bi]
