@@ -106,6 +106,11 @@ int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);
  * ms[3] = whole pass (averages per pass, milliseconds). */
 int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop, int reps, float *ms);
 
+/* Profiling aid, never used by the product path: bit mask of kernel phases to skip
+ * (1 meshlet culling onward, 2 vertex shading onward, 4 triangle set-up, 8 pixel loop, 16 loss pass).
+ * Results are meaningless while a bit is set. */
+int rope_debug_skip(rope_ctx *ctx, int mask);
+
 #ifdef __cplusplus
 }
 #endif

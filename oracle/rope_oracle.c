@@ -211,8 +211,17 @@ void orc_raster(const float *verts, const int32_t *faces, const int32_t *vtx_off
             int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1;
             int64_t b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1;
             int64_t b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
-            double inv = 1.0 / (double)area2;
-            double d0 = (double)a.d, e1 = (double)b.d - (double)a.d, e2 = (double)c.d - (double)a.d;
+            /* window-depth plane in float32, anchored at the pixel that holds vertex a */
+            int32_t pxa = a.X >> 8, pya = a.Y >> 8;
+            int64_t fxa = (int64_t)pxa * SUBPIX + HALFPIX, fya = (int64_t)pya * SUBPIX + HALFPIX;
+            int64_t E20a = edge_fn(c.X, c.Y, a.X, a.Y, fxa, fya), E01a = edge_fn(a.X, a.Y, b.X, b.Y, fxa, fya);
+            float inv = 1.0f / (float)(double)area2;
+            float e1 = b.d - a.d, e2 = c.d - a.d;
+            float fA20 = (float)(-(a.Y - c.Y)), fB20 = (float)(a.X - c.X);
+            float fA01 = (float)(-(b.Y - a.Y)), fB01 = (float)(b.X - a.X);
+            float gx = (((e1 * fA20) + (e2 * fA01)) * inv) * 256.0f;
+            float gy = (((e1 * fB20) + (e2 * fB01)) * inv) * 256.0f;
+            float dc = a.d + (((e1 * (float)(double)E20a) + (e2 * (float)(double)E01a)) * inv);
             for (int py = y0; py <= y1; py++) {
                 int64_t fy = (int64_t)py * SUBPIX + HALFPIX;
                 for (int px = x0; px <= x1; px++) {
@@ -221,10 +230,9 @@ void orc_raster(const float *verts, const int32_t *faces, const int32_t *vtx_off
                     int64_t E12 = edge_fn(b.X, b.Y, c.X, c.Y, fx, fy);
                     int64_t E20 = edge_fn(c.X, c.Y, a.X, a.Y, fx, fy);
                     if ((E01 + b01) < 0 || (E12 + b12) < 0 || (E20 + b20) < 0) continue;
-                    double l1 = (double)E20 * inv, l2 = (double)E01 * inv;
-                    double dd = d0 + (l1 * e1 + l2 * e2);
-                    double qd = dd * 16777215.0 + 0.5;
-                    uint32_t d24 = qd < 0.0 ? 0u : (qd >= 16777215.0 ? D24_MAX : (uint32_t)qd);
+                    float d = fmaf(gx, (float)(px - pxa), fmaf(gy, (float)(py - pya), dc));
+                    float qf = rintf(d * 16777215.0f);
+                    uint32_t d24 = !(qf >= 0.0f) ? 0u : (qf >= 16777215.0f ? D24_MAX : (uint32_t)qf);
                     if (d24 >= D24_MAX) continue;            /* GL_LESS against the cleared 1.0 */
                     uint32_t k = (d24 << 8) | (uint32_t)l;
                     uint32_t *dst = key + (size_t)(H - 1 - py) * W + px;

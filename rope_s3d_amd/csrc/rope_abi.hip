@@ -419,6 +419,13 @@ extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
     return ROPE_OK;
 }
 
+extern "C" int rope_debug_skip(rope_ctx *c, int mask)
+{
+    if (!c) return ROPE_E_ARG;
+    c->fp.debug = mask;
+    return ROPE_OK;
+}
+
 extern "C" int rope_profile_eval(rope_ctx *c, int n_render, int loss, const int32_t *crop, int reps, float *ms)
 {
     if (!c) return ROPE_E_ARG;

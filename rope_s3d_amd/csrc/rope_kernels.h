@@ -7,9 +7,12 @@
 
 namespace rope {
 
-constexpr int TILE_W = 64;
+constexpr int TILE_W = 128;
 constexpr int TILE_H = 64;
-constexpr int MAX_MESHLETS = 4096;        // capacity of the per-tile meshlet list in LDS
+constexpr int NWAVES = 8;                 // waves per workgroup of the raster kernel
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int SMALL_TRI_PIXELS = 16;      // bounding boxes up to this many samples are walked by one lane
+constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet list in LDS
 constexpr int MESHLET_MAX_VERTS = 128;
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t D24_MAX = 16777215u;
@@ -24,6 +27,7 @@ struct FrameParams {
     int W, H, tiles_x, tiles_y;
     int r0, r1, c0, c1;                   // rows/cols taking part in the loss (whole frame unless lookup crop)
     float c_num, c_sum, c_dif;            // 2nf, f+n, f-n as float32 (pyrender depth read-back)
+    int debug;                            // profiling only: bit mask of phases to skip (0 in production)
 };
 
 struct RobotParams {

@@ -214,7 +214,7 @@ __device__ static inline void score_tile(const uint32_t *tile /* LDS or nullptr 
 // Sums of every tile when nothing is rendered into it; the raster kernel adds
 // (actual - empty) for the tiles it touches, finalize adds the frame total back.
 template <int LOSS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(NTHREADS)
 empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *__restrict__ t32,
                   uint64_t *__restrict__ empty_sums /* n_tiles x SUM_WORDS */)
 {
@@ -291,11 +291,102 @@ __device__ static inline bool sphere_hits_rect(const float *m, const float *sc, 
     return !(sxhi < px0 || sxlo > px1 + 1.0f || syhi < py0 || sylo > py1 + 1.0f);
 }
 
+// Tile frame: u = px - col0 in [0,TILE_W), v = py - vy0 in [0,TILE_H) with py the GL window
+// row (y up); LDS slot = (TILE_H-1-v)*TILE_W + u, i.e. image rows top-down.
+struct TileFrame {
+    int col0, vy0;            // window coordinates of (u,v) = (0,0); vy0 may be negative on the last tile row
+    int u1, v0;               // valid samples: u in [0,u1], v in [v0,TILE_H-1]
+};
+
+// Half-space of edge a->b for tile-relative integer sample coordinates:
+//   covered side  <=>  A*u + B*v >= K        (exactly edge_fn(...)+bias >= 0 at the sample centre)
+struct Edge { int32_t A, B, K; };
+constexpr int32_t EDGE_COEF_LIMIT = 1 << 22;     // |A|,|B| below this keep A*u+B*v inside int32
+constexpr int64_t EDGE_K_LIMIT = 1 << 30;
+
+__device__ static inline Edge make_edge(int32_t ax, int32_t ay, int32_t bx, int32_t by, const TileFrame &tf)
+{
+    Edge e;
+    e.A = -(by - ay);
+    e.B = bx - ax;
+    const int64_t bias = owns(ax, ay, bx, by) ? 0 : -1;
+    const int64_t Cc = (int64_t)128 * ((int64_t)e.A + e.B) - (int64_t)e.A * ax - (int64_t)e.B * ay + bias;
+    int64_t K = -(Cc >> 8) - (int64_t)e.A * tf.col0 - (int64_t)e.B * tf.vy0;
+    K = K > EDGE_K_LIMIT ? EDGE_K_LIMIT : (K < -EDGE_K_LIMIT ? -EDGE_K_LIMIT : K);
+    e.K = (int32_t)K;
+    return e;
+}
+
+// Window-depth plane of a front-facing triangle, anchored at the pixel that holds vertex a.
+struct Plane { float gx, gy, dc; };
+
+__device__ static inline Plane make_plane(const SVert &a, const SVert &b, const SVert &c, int64_t area2)
+{
+    const int32_t pxa = a.X >> 8, pya = a.Y >> 8;
+    const int32_t fxa = pxa * 256 + 128, fya = pya * 256 + 128;
+    const int64_t E20a = edge_fn(c.X, c.Y, a.X, a.Y, fxa, fya), E01a = edge_fn(a.X, a.Y, b.X, b.Y, fxa, fya);
+    const float inv = 1.0f / (float)(double)area2;
+    const float e1 = b.d - a.d, e2 = c.d - a.d;
+    const float fA20 = (float)(-(a.Y - c.Y)), fB20 = (float)(a.X - c.X);
+    const float fA01 = (float)(-(b.Y - a.Y)), fB01 = (float)(b.X - a.X);
+    Plane p;
+    p.gx = (((e1 * fA20) + (e2 * fA01)) * inv) * 256.0f;
+    p.gy = (((e1 * fB20) + (e2 * fB01)) * inv) * 256.0f;
+    p.dc = a.d + (((e1 * (float)(double)E20a) + (e2 * (float)(double)E01a)) * inv);
+    return p;
+}
+
+__device__ static inline void depth_test_write(uint32_t *tile, int u, int v, const Plane &pl, float dx, float dy, uint32_t link)
+{
+    const float d = fmaf(pl.gx, dx, fmaf(pl.gy, dy, pl.dc));
+    const float qf = rintf(d * 16777215.0f);
+    const uint32_t d24 = !(qf >= 0.0f) ? 0u : (qf >= 16777215.0f ? D24_MAX : (uint32_t)qf);
+    if (d24 < D24_MAX)                              // GL_LESS against the cleared depth of 1.0
+        atomicMin(&tile[(TILE_H - 1 - v) * TILE_W + u], (d24 << 8) | link);
+}
+
+// smallest u with A*u >= n (A > 0), estimate by float then exact fix-up; clamped to [-5, TILE_W+4]
+__device__ static inline int ceil_div_pos(int32_t n, int32_t A, float rcpA)
+{
+    float q = ceilf((float)n * rcpA);
+    q = fminf(fmaxf(q, -3.0f), (float)(TILE_W + 2));
+    int u = (int)q;
+    u += (A * u < n);
+    u += (A * u < n);
+    u -= (A * (u - 1) >= n);
+    u -= (A * (u - 1) >= n);
+    return u;
+}
+
+// largest u with A*u <= n (A > 0)
+__device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
+{
+    float q = floorf((float)n * rcpA);
+    q = fminf(fmaxf(q, -3.0f), (float)(TILE_W + 2));
+    int u = (int)q;
+    u -= (A * u > n);
+    u -= (A * u > n);
+    u += (A * (u + 1) <= n);
+    u += (A * (u + 1) <= n);
+    return u;
+}
+
+// Samples of row v covered by the half-space: narrows [lo,hi].
+__device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
+{
+    const int32_t n = e.K - e.B * v;               // A*u >= n
+    if (e.A > 0) lo = max(lo, ceil_div_pos(n, e.A, __builtin_amdgcn_rcpf((float)e.A)));
+    else if (e.A < 0) hi = min(hi, floor_div_pos(-n, -e.A, __builtin_amdgcn_rcpf((float)(-e.A))));
+    else if (n > 0) hi = -1;
+}
+
+struct QEntry { uint32_t packed; float gx, gy, dc; };   // queued triangle: vertex indices + depth plane
+
 // MODE_SCORE: reduce the loss and add (actual - empty) into the candidate's sums.
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
 template <int LOSS, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(NTHREADS)
 raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *__restrict__ mvp_all,
                     const float *__restrict__ scale_all, const uint64_t *__restrict__ tq,
                     const float *__restrict__ t32, const uint64_t *__restrict__ empty_sums,
@@ -306,7 +397,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
     __shared__ float s_scale[ROPE_MAX_LINKS * 4];
     __shared__ uint16_t s_list[MAX_MESHLETS];
     __shared__ int s_count;
-    __shared__ SVert s_vert[4][MESHLET_MAX_VERTS];
+    __shared__ SVert s_vert[NWAVES][MESHLET_MAX_VERTS];
+    __shared__ QEntry s_queue[NWAVES][64];
+    __shared__ int s_qoff[NWAVES][64];
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -317,6 +410,11 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
     const int wx0 = col0, wx1 = min(col0 + TILE_W, fp.W) - 1;
     const int wy1 = fp.H - 1 - row0, wy0 = max(fp.H - row0 - TILE_H, 0);
     const float hw = 0.5f * (float)fp.W, hh = 0.5f * (float)fp.H;
+    TileFrame tf;
+    tf.col0 = col0;
+    tf.vy0 = fp.H - row0 - TILE_H;
+    tf.u1 = wx1 - col0;
+    tf.v0 = wy0 - tf.vy0;
 
     if (tid < n_render * 16) s_mvp[tid] = mvp_all[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
     if (tid < n_render * 4) s_scale[tid] = scale_all[((size_t)cand * ROPE_MAX_LINKS) * 4 + tid];
@@ -332,9 +430,11 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
                              (float)wx0, (float)wx1, (float)wy0, (float)wy1))
             link_hit |= 1u << l;
     }
-    if (link_hit) {
+    if (!link_hit) return;                        // uniform: every thread tested the same six spheres
+    if (fp.debug & 1) return;
+    {
         const int m_end = rp.link_first[n_render];
-        for (int m = tid; m < m_end; m += blockDim.x) {
+        for (int m = tid; m < m_end; m += NTHREADS) {
             const uint4 h0 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m];
             const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
             const int l = (int)h1.w;
@@ -347,78 +447,154 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
             }
         }
     }
-    for (int i = tid; i < TILE_W * TILE_H; i += blockDim.x) tile[i] = KEY_EMPTY;
+    for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
     __syncthreads();
     const int n_list = s_count;
     if (n_list == 0) return;                      // nothing can land in this tile: its sums stay "empty"
 
     // --- one meshlet per wave at a time
-    for (int li = wave; li < n_list; li += 4) {
+    SVert *const wv = s_vert[wave];
+    QEntry *const wq = s_queue[wave];
+    int *const woff = s_qoff[wave];
+    for (int li = wave; li < n_list; li += NWAVES) {
         const int m = s_list[li];
         const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
-        const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16), l = (int)h1.w;
+        const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
+        const uint32_t l = h1.w;
         const float *mm = s_mvp + 16 * l;
+        if (fp.debug & 2) continue;
         for (int v = lane; v < nv; v += 64) {
             const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
-            s_vert[wave][v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
+            wv[v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int t = lane; t < nt; t += 64) {
-            const uint32_t packed = rp.ml_tris[t0 + t];
-            const SVert a = s_vert[wave][packed & 0xFF], b = s_vert[wave][(packed >> 8) & 0xFF],
-                        c = s_vert[wave][(packed >> 16) & 0xFF];
-            if (a.X == SV_BAD || b.X == SV_BAD || c.X == SV_BAD) continue;
-            const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
-            if (area2 <= 0) continue;             // back-facing or degenerate
-            const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
-            const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
-            const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
-            const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
-            if (x0 > x1 || y0 > y1) continue;     // no sample centre inside the bounding box
-            const int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1;
-            const int64_t b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1;
-            const int64_t b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
-            const double inv = 1.0 / (double)area2;
-            const double d0 = (double)a.d, e1 = (double)b.d - (double)a.d, e2 = (double)c.d - (double)a.d;
-            // per-pixel x step of each edge function
-            const int64_t s01 = -(int64_t)(b.Y - a.Y) * 256, s12 = -(int64_t)(c.Y - b.Y) * 256, s20 = -(int64_t)(a.Y - c.Y) * 256;
-            for (int py = y0; py <= y1; py++) {
-                const int32_t fy = py * 256 + 128, fx0 = x0 * 256 + 128;
-                int64_t E01 = edge_fn(a.X, a.Y, b.X, b.Y, fx0, fy);
-                int64_t E12 = edge_fn(b.X, b.Y, c.X, c.Y, fx0, fy);
-                int64_t E20 = edge_fn(c.X, c.Y, a.X, a.Y, fx0, fy);
-                uint32_t *trow = tile + (fp.H - 1 - py - row0) * TILE_W - col0;
-                for (int px = x0; px <= x1; px++, E01 += s01, E12 += s12, E20 += s20) {
-                    if (((E01 + b01) | (E12 + b12) | (E20 + b20)) < 0) continue;
-                    const double l1 = (double)E20 * inv, l2 = (double)E01 * inv;
-                    const double dd = d0 + (l1 * e1 + l2 * e2);
-                    const double qd = dd * 16777215.0 + 0.5;
-                    const uint32_t d24 = qd < 0.0 ? 0u : (qd >= 16777215.0 ? D24_MAX : (uint32_t)qd);
-                    if (d24 >= D24_MAX) continue; // GL_LESS against the cleared depth of 1.0
-                    atomicMin(&trow[px], (d24 << 8) | (uint32_t)l);
+        if (fp.debug & 4) continue;
+        for (int tb = 0; tb < nt; tb += 64) {
+            // ---- per-lane set-up: cull, classify, rasterise the small ones in place
+            int rows = 0;                          // > 0: queued for the row-parallel pass
+            QEntry qe;
+            const int t = tb + lane;
+            if (t < nt) {
+                const uint32_t packed = rp.ml_tris[t0 + t];
+                const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
+                if (a.X != SV_BAD && b.X != SV_BAD && c.X != SV_BAD) {
+                    const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
+                    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
+                    const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
+                    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
+                    const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
+                    // front-facing (CCW) with at least one sample centre inside its bounding box
+                    if (area2 > 0 && x0 <= x1 && y0 <= y1 && !(fp.debug & 8)) {
+                        const Plane pl = make_plane(a, b, c, area2);
+                        const int32_t pxa = a.X >> 8, pya = a.Y >> 8;
+                        const Edge e0 = make_edge(a.X, a.Y, b.X, b.Y, tf), e1 = make_edge(b.X, b.Y, c.X, c.Y, tf),
+                                   e2 = make_edge(c.X, c.Y, a.X, a.Y, tf);
+                        const int32_t big = max(max(abs(e0.A), abs(e0.B)), max(max(abs(e1.A), abs(e1.B)), max(abs(e2.A), abs(e2.B))));
+                        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+                        if (big >= EDGE_COEF_LIMIT) {
+                            // enormous triangle (edge extent >= 16384 px): exact 64-bit walk, one lane
+                            const int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1, b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1,
+                                          b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
+                            for (int py = y0; py <= y1; py++)
+                                for (int px = x0; px <= x1; px++) {
+                                    const int32_t fx = px * 256 + 128, fy = py * 256 + 128;
+                                    if (((edge_fn(a.X, a.Y, b.X, b.Y, fx, fy) + b01) | (edge_fn(b.X, b.Y, c.X, c.Y, fx, fy) + b12) |
+                                         (edge_fn(c.X, c.Y, a.X, a.Y, fx, fy) + b20)) < 0) continue;
+                                    depth_test_write(tile, px - col0, py - tf.vy0, pl, (float)(px - pxa), (float)(py - pya), l);
+                                }
+                        } else if (w * h <= SMALL_TRI_PIXELS) {
+                            for (int py = y0; py <= y1; py++) {
+                                const int v = py - tf.vy0;
+                                for (int px = x0; px <= x1; px++) {
+                                    const int u = px - col0;
+                                    if (e0.A * u + e0.B * v >= e0.K && e1.A * u + e1.B * v >= e1.K && e2.A * u + e2.B * v >= e2.K)
+                                        depth_test_write(tile, u, v, pl, (float)(px - pxa), (float)(py - pya), l);
+                                }
+                            }
+                        } else {
+                            rows = h;
+                            qe.packed = packed; qe.gx = pl.gx; qe.gy = pl.gy; qe.dc = pl.dc;
+                        }
+                    }
                 }
             }
+            // ---- queue the larger triangles, then spread their rows over the lanes
+            const unsigned long long qmask = __ballot(rows > 0);
+            if (qmask == 0) continue;
+            const int qn = __popcll(qmask);
+            const int qpos = __popcll(qmask & ((1ull << lane) - 1));
+            if (rows > 0) wq[qpos] = qe;
+            // exclusive prefix of rows in queue order: lane i scans entry i
+            int incl;
+            {
+                // hand entry order to lanes 0..qn-1: lane with rows>0 publishes rows at its queue slot
+                if (rows > 0) woff[qpos] = rows;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                incl = lane < qn ? woff[lane] : 0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += o;
+                }
+            }
+            const int total = __shfl(incl, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < qn) woff[lane] = incl;      // inclusive ends: entry e owns items [woff[e-1], woff[e])
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int base = 0; base < total; base += 64) {
+                const int item = base + lane;
+                if (item < total) {
+                    // first entry whose inclusive end exceeds item
+                    int lo = 0, hi = qn - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (woff[mid] > item) hi = mid; else lo = mid + 1;
+                    }
+                    const int r = item - (lo > 0 ? woff[lo - 1] : 0);
+                    const QEntry e = wq[lo];
+                    const SVert a = wv[e.packed & 0xFF], b = wv[(e.packed >> 8) & 0xFF], c = wv[(e.packed >> 16) & 0xFF];
+                    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
+                    const int32_t minY = min(a.Y, min(b.Y, c.Y));
+                    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
+                    const int y0 = max(-((-(minY - 128)) >> 8), wy0);
+                    const int py = y0 + r, v = py - tf.vy0;
+                    int ulo = x0 - col0, uhi = x1 - col0;
+                    clip_span(make_edge(a.X, a.Y, b.X, b.Y, tf), v, ulo, uhi);
+                    clip_span(make_edge(b.X, b.Y, c.X, c.Y, tf), v, ulo, uhi);
+                    clip_span(make_edge(c.X, c.Y, a.X, a.Y, tf), v, ulo, uhi);
+                    const Plane pl = {e.gx, e.gy, e.dc};
+                    const float dy = (float)(py - (a.Y >> 8));
+                    const int dxa = col0 - (a.X >> 8);
+                    for (int u = ulo; u <= uhi; u++) depth_test_write(tile, u, v, pl, (float)(u + dxa), dy, l);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 
     if (MODE == MODE_DUMP) {
-        for (int i = tid; i < TILE_W * TILE_H; i += blockDim.x) {
+        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) {
             int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
             if (row < fp.H && col < fp.W) key_out[(size_t)row * fp.W + col] = tile[i];
         }
         return;
     }
     if (MODE == MODE_COVER) {
-        for (int i = tid; i < TILE_W * TILE_H; i += blockDim.x) {
+        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) {
             int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
             if (row < fp.H && col < fp.W && tile[i] != KEY_EMPTY) cover[(size_t)row * fp.W + col] = 1;
         }
         return;
     }
+    if (fp.debug & 16) return;
     score_tile<LOSS>(tile, row0, col0, fp, n_render, tq, t32, lds_sums);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
@@ -524,18 +700,19 @@ static hipError_t launch_raster_mode(int loss, dim3 grid, hipStream_t st, const 
                                      const float *t32, const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out,
                                      uint8_t *cover)
 {
-    switch (loss) {
+    if (MODE != MODE_SCORE) loss = ROPE_LOSS_DEPTH;
+    switch (MODE == MODE_SCORE ? loss : ROPE_LOSS_DEPTH) {
     case ROPE_LOSS_DEPTH:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_DEPTH, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_DEPTH, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
         break;
     case ROPE_LOSS_FULL:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_FULL, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_FULL, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
         break;
     case ROPE_LOSS_LOOKUP:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_LOOKUP, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_LOOKUP, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
         break;
     default:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_TSWEEP, MODE>), grid, dim3(256), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_TSWEEP, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
         break;
     }
     return hipGetLastError();
@@ -563,10 +740,10 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
 {
     dim3 grid(fp.tiles_x * fp.tiles_y);
     switch (loss) {
-    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
-    case ROPE_LOSS_FULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_FULL>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
-    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_LOOKUP>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
-    default: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(256), 0, st, fp, tq, t32, empty_sums); break;
+    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
+    case ROPE_LOSS_FULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_FULL>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
+    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_LOOKUP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
+    default: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
     }
     hipLaunchKernelGGL(total_tiles_kernel, dim3(1), dim3(64), 0, st, empty_sums, fp.tiles_x * fp.tiles_y, total);
     return hipGetLastError();

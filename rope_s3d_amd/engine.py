@@ -20,7 +20,7 @@ TQ_MAX = (1 << 39) - 1
 ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
-    'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval')
+    'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip')
 
 
 class EngineUnavailable(RuntimeError):
@@ -65,6 +65,7 @@ def load_library(path: str = None):
     lib.rope_coverage.argtypes = [vp, vp, i32, i32, vp]
     lib.rope_debug_mvp.argtypes = [vp, vp, i32, i32]
     lib.rope_profile_eval.argtypes = [vp, i32, i32, vp, i32, vp]
+    lib.rope_debug_skip.argtypes = [vp, i32]
     _lib = lib
     return lib
 
@@ -196,6 +197,9 @@ class Engine:
         out = np.empty((C_, n_render, 16), np.float32)
         self._check(self._lib.rope_debug_mvp(self._ctx, _p(out), int(C_), int(n_render)), 'rope_debug_mvp')
         return out
+
+    def debug_skip(self, mask: int):
+        self._check(self._lib.rope_debug_skip(self._ctx, int(mask)), 'rope_debug_skip')
 
     def profile_eval(self, n_render: int, loss: int, crop=None, reps: int = 10):
         """-> dict of average milliseconds per pass: fk, raster, finalize, total (HIP events on the engine stream)."""
