@@ -44,6 +44,7 @@ def lib():
         _LIB.orc_eval_batch.argtypes = ([C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
                                         + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int])
         _LIB.orc_sum_words.restype = C.c_int
+        _LIB.orc_coverage_batch.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     return _LIB
 
 
@@ -137,6 +138,15 @@ class Oracle:
                              self.znear, self.zfar, int(loss), int(n), _p(tq), _p(t32), _p(crop_a), _p(lf),
                              _p(cand), Cn, _p(err), _p(sums), int(threads))
         return (err, sums) if want_sums else err
+
+
+    def coverage(self, cand, n, threads=1) -> np.ndarray:
+        cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
+        cover = np.zeros((self.H, self.W), np.uint8)
+        lib().orc_coverage_batch(_p(self.verts), _p(self.faces), _p(self.vtx_off), _p(self.tri_off),
+                                 _p(self.joint_fixed), _p(self.joint_axes), _p(self.PV), self.W, self.H, int(n),
+                                 _p(cand), len(cand), _p(cover), int(threads))
+        return cover
 
 
 # ---------------------------------------------------------------- numpy literal restatements

@@ -402,4 +402,44 @@ void orc_eval_batch(const float *verts, const int32_t *faces, const int32_t *vtx
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
 }
 
+/* OR over candidates of "pixel covered" (Crop._create's depth-sum loop, robotpose/crop.py:60-81). */
+typedef struct { const job_t *j; uint8_t *cover; } cov_job;
+
+static void *cov_worker(void *arg)
+{
+    cov_job *cj = (cov_job *)arg;
+    const job_t *j = cj->j;
+    size_t n = (size_t)j->W * j->H;
+    uint32_t *key = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    for (int c = j->tid; c < j->C; c += j->nthreads) {
+        double fk[7 * 12]; float mvp[MAX_LINKS * 16];
+        orc_fk(j->joint_fixed, j->axes, j->cand + 6 * c, fk);
+        orc_mvp(j->PV, fk, j->n_render, mvp);
+        orc_raster(j->verts, j->faces, j->vtx_off, j->tri_off, j->n_render, mvp, j->W, j->H, key);
+        for (size_t i = 0; i < n; i++)
+            if (key[i] != KEY_EMPTY) cj->cover[i] = 1;      /* racing writers all store 1 */
+    }
+    free(key);
+    return NULL;
+}
+
+void orc_coverage_batch(const float *verts, const int32_t *faces, const int32_t *vtx_off, const int32_t *tri_off,
+                        const double *joint_fixed, const double *axes, const double *PV, int W, int H,
+                        int n_render, const double *cand, int C, uint8_t *cover, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    job_t jobs[256]; cov_job cj[256]; pthread_t th[256];
+    memset(cover, 0, (size_t)W * H);
+    for (int t = 0; t < nthreads; t++) {
+        job_t j = {verts, faces, vtx_off, tri_off, joint_fixed, axes, PV, W, H, 0.0, 0.0, 0, n_render,
+                   NULL, NULL, NULL, NULL, cand, C, NULL, NULL, t, nthreads};
+        jobs[t] = j;
+        cj[t].j = &jobs[t];
+        cj[t].cover = cover;
+    }
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, cov_worker, &cj[t]);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+
 int orc_sum_words(void) { return SUM_WORDS; }

@@ -505,6 +505,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
                                     depth_test_write(tile, px - col0, py - tf.vy0, pl, (float)(px - pxa), (float)(py - pya), l);
                                 }
                         } else if (w * h <= SMALL_TRI_PIXELS) {
+                            if (!(fp.debug & 32))
                             for (int py = y0; py <= y1; py++) {
                                 const int v = py - tf.vy0;
                                 for (int px = x0; px <= x1; px++) {
@@ -522,7 +523,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
             }
             // ---- queue the larger triangles, then spread their rows over the lanes
             const unsigned long long qmask = __ballot(rows > 0);
-            if (qmask == 0) continue;
+            if (qmask == 0 || (fp.debug & 64)) continue;
             const int qn = __popcll(qmask);
             const int qpos = __popcll(qmask & ((1ull << lane) - 1));
             if (rows > 0) wq[qpos] = qe;

@@ -1,0 +1,2 @@
+from .predict import Predictor
+from .synthetic import SyntheticPredictor

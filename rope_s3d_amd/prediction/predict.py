@@ -1,0 +1,378 @@
+"""Joint-angle prediction by render-and-compare, driven from Python, evaluated on the GPU.
+
+`Predictor` keeps the reference's constructor and `run` signature
+(robotpose/prediction/predict.py:37-48,127,375) so predict_dataset.py / predict_live.py /
+SyntheticPredictor call it unchanged.  The stage machine below follows the reference's
+control flow decision for decision (quirks included, each cited where it appears); what
+changes is how a candidate is evaluated: every `render_at_pos` + `_error` pair of the
+reference (predict.py:159-161,475-509) becomes one row of a batch handed to the HIP
+engine, which does FK, rasterisation and the error reduction on the device.
+"""
+import warnings
+from typing import Callable, Optional
+
+import numpy as np
+
+from ..constants import DEFAULT_CAMERA_POSE, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
+from ..crop import Crop
+from ..engine import LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, pack_target
+from ..imgproc import dilate, erode, resize_linear
+from ..projection import Intrinsics
+from ..simulation.lookup import RobotLookupManager
+from ..simulation.render import Renderer
+from ..urdf import URDFReader
+from .stages import Descent, InterpolativeSweep, Lookup, SFlip, TensorSweep, getStages
+
+HISTORY_LENGTH = 5      # predict.py:30
+
+
+def cubic_interp(x: np.ndarray, y: np.ndarray, xq: np.ndarray) -> np.ndarray:
+    """interp1d(x, y, kind='cubic')(xq) — the not-a-knot cubic spline of predict.py:310.
+
+    scipy (the reference's own dependency) is used when importable; otherwise the same spline
+    is solved directly."""
+    try:
+        from scipy.interpolate import interp1d
+        return interp1d(x, y, kind='cubic')(xq)
+    except ImportError:
+        return _not_a_knot(np.asarray(x, float), np.asarray(y, float), np.asarray(xq, float))
+
+
+def _not_a_knot(x, y, xq):
+    n = len(x)
+    h = np.diff(x)
+    A = np.zeros((n, n))
+    r = np.zeros(n)
+    for i in range(1, n - 1):
+        A[i, i - 1], A[i, i], A[i, i + 1] = h[i - 1], 2 * (h[i - 1] + h[i]), h[i]
+        r[i] = 6 * ((y[i + 1] - y[i]) / h[i] - (y[i] - y[i - 1]) / h[i - 1])
+    A[0, 0], A[0, 1], A[0, 2] = h[1], -(h[0] + h[1]), h[0]
+    A[-1, -3], A[-1, -2], A[-1, -1] = h[-1], -(h[-2] + h[-1]), h[-2]
+    M = np.linalg.solve(A, r)
+    i = np.clip(np.searchsorted(x, xq, side='right') - 1, 0, n - 2)
+    t0, t1 = xq - x[i], x[i + 1] - xq
+    return (M[i] * t1 ** 3 + M[i + 1] * t0 ** 3) / (6 * h[i]) + (y[i] / h[i] - M[i] * h[i] / 6) * t1 \
+        + (y[i + 1] / h[i] - M[i + 1] * h[i] / 6) * t0
+
+
+class Predictor:
+
+    def __init__(self,
+                 camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
+                 ds_factor: int = 8,
+                 preview: bool = False,
+                 save_to: str = None,
+                 do_angles: str = 'SLU',
+                 min_angle_inc: np.ndarray = np.array([.005] * 6),
+                 base_intrin: str = '1280_720_color',
+                 model_ds: str = 'set10',
+                 color_dict: dict = None,
+                 *,
+                 device: int = 0,
+                 segmenter: Optional[Callable] = None,
+                 lookup_divisions=None):
+        """Reference parameters as in predict.py:38-70.  Extra keyword-only arguments:
+
+        device            HIP device ordinal of the engine context
+        segmenter         callable(colour uint8 HxWx3) -> {'class_ids', 'scores', 'masks' (H,W,K) bool};
+                          stands in for pixellib's segmentImage (predict.py:416) when color_dict is None
+        lookup_divisions  explicit lookup grid divisions (six ints or one int for every lookup joint);
+                          default: the reference's size rule with an 8 GiB budget (simulation/lookup.py)
+        """
+        if preview:
+            raise NotImplementedError("preview needs an OpenCV window (ProjectionViz, predict.py:517-602): out of scope")
+        self.ds_factor, self.preview = ds_factor, preview
+        self.do_angles = do_angles.upper()
+        self.min_ang_inc, self.history_length = np.asarray(min_angle_inc, dtype=float), HISTORY_LENGTH
+
+        self.intrinsics = Intrinsics(base_intrin)
+        self.intrinsics.downscale(ds_factor)
+        self.u_reader = URDFReader()
+        self.renderer = Renderer('seg', camera_pose, self.intrinsics, device=device)
+        self.engine = self.renderer.engine
+
+        self.synthetic = color_dict is not None
+        self.classes = ["BG"]
+        self.classes.extend(self.u_reader.mesh_names[:6])
+        self.link_names = self.classes[1:]
+
+        if self.synthetic:
+            self.color_dict = color_dict
+        else:
+            self.seg = segmenter
+            self.model_ds = model_ds
+        self._lookup_divisions = lookup_divisions
+        self.camera_pose = None
+        self.changeCameraPose(camera_pose)
+        self.evaluations = 0          # candidates rendered+scored, for throughput accounting
+
+    # ------------------------------------------------------------------ camera / lookup grid
+    def changeCameraPose(self, camera_pose):
+        self.camera_pose = np.asarray(camera_pose, dtype=float).copy()
+        self.renderer.setCameraPose(self.camera_pose)
+        self.crops = Crop(self.camera_pose, self.intrinsics, renderer=self.renderer)
+        self._loadLookup()
+
+    def _loadLookup(self):
+        lm = RobotLookupManager(self.u_reader.joint_limits)
+        div = self._lookup_divisions
+        if div is not None and np.ndim(div) == 0:
+            from ..utils import str_to_arr
+            d = np.zeros(6, int)
+            d[str_to_arr(LOOKUP_JOINTS)] = int(div)
+            div = d
+        self.lookup_angles, _ = lm.get(self.crops.size(LOOKUP_NUM_RENDERED), LOOKUP_JOINTS, divisions=div)
+        self.lookup_crop = np.asarray(self.crops[LOOKUP_NUM_RENDERED], dtype=np.int32)
+
+    def _setStages(self):
+        self.stages = getStages(self.do_angles)
+        if self.stages is None:
+            raise ValueError(f"Stages not defined for joint set {self.do_angles}. "
+                             "Please define in rope_s3d_amd/prediction/stages.py.")
+
+    # ------------------------------------------------------------------ target preparation
+    def _downsample(self, base: np.ndarray, factor: int) -> np.ndarray:
+        h, w = base.shape[0] // factor, base.shape[1] // factor
+        return resize_linear(base, w, h)                # cv2.resize(base, (w, h)), predict.py:378-381
+
+    def _reorganize_by_link(self, data: dict) -> dict:
+        """Merge instances of one class: OR the masks, keep the best score (predict.py:383-395)."""
+        out = {}
+        ids = list(data['class_ids'])
+        for idx, cid in enumerate(ids):
+            name = self.classes[cid]
+            if cid not in ids[:idx]:
+                out[name] = {'confidence': data['scores'][idx], 'mask': np.array(data['masks'][..., idx], dtype=bool)}
+            else:
+                out[name]['mask'] = out[name]['mask'] | np.asarray(data['masks'][..., idx], dtype=bool)
+                out[name]['confidence'] = max(out[name]['confidence'], data['scores'][idx])
+        return out
+
+    def _upload_target(self, tgt_depth: np.ndarray, lookup_depth: np.ndarray, masks: dict):
+        """Hand the frame's target to the engine: what _load_target caches in the reference
+        (predict.py:397-413) becomes one packed plane + per-link flags in HBM."""
+        self._tgt_depth = tgt_depth
+        self._lookup_depth_f32 = np.ascontiguousarray(lookup_depth, dtype=np.float32)
+        self._masked_targets, self._target_masks = {}, {}
+        bits = np.zeros(tgt_depth.shape, np.uint64)
+        flags = np.zeros(8, np.uint8)
+        for l, link in enumerate(self.link_names):
+            if link in masks:
+                m = np.asarray(masks[link], dtype=bool)
+                tm = m * tgt_depth
+                self._masked_targets[link], self._target_masks[link] = tm, m
+                bits |= m.astype(np.uint64) << np.uint64(l)
+                flags[l] |= 1
+                if np.sum(tm != 0) > (.05 * np.sum(m)):          # predict.py:495, a target-only fact
+                    flags[l] |= 2
+        self._tq = pack_target(tgt_depth, bits)
+        self._flags = flags
+        self.engine.set_target(self._tq, self._lookup_depth_f32, flags)
+
+    def _segmentLoad(self, target_color, target_depth):
+        """Segmentation path (predict.py:415-442).  NB: like the reference, zeroes target_depth in place."""
+        if self.seg is None:
+            raise NotImplementedError(
+                "no segmenter: pass segmenter=callable(colour)->{'class_ids','scores','masks'} (the Mask R-CNN "
+                "stage on PyTorch-ROCm is SURVEY §8f rank 1), or color_dict for synthetic input")
+        r = self.seg(self._downsample(target_color, self.ds_factor))
+        seg = self._reorganize_by_link(r)
+
+        def body(keys):
+            new = np.zeros(target_depth.shape)
+            for k in keys:
+                new += seg[k]['mask']
+            return erode(dilate(new, 8), 7).astype(bool).astype(float)      # predict.py:419-428
+
+        target_depth *= body(seg.keys())
+        lookup_depth = target_depth.copy()
+        lookup_depth *= body([k for k in seg if k in self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED]])
+        self._upload_target(target_depth, lookup_depth, {k: v['mask'] for k, v in seg.items()})
+        return target_depth
+
+    def _loadSynthetic(self, target_color, target_depth):
+        """Synthetic path: link masks are read off channel 0 of the colour render (predict.py:445-469)."""
+        target_color = self._downsample(target_color, self.ds_factor)
+        blue = target_color[..., 0]
+        new = np.zeros(target_depth.shape)
+        for k in self.color_dict:
+            if k in self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED]:
+                new += blue == self.color_dict[k][0]
+        lookup_depth = target_depth * new.astype(bool).astype(float)
+        masks = {}
+        for link in self.link_names:
+            m = blue == self.color_dict[link][0]
+            if np.sum(m.astype(float)) > 0:
+                masks[link] = m
+        self._upload_target(target_depth, lookup_depth, masks)
+        return target_depth
+
+    # ------------------------------------------------------------------ evaluation
+    def _errors(self, n_render: int, candidates: np.ndarray) -> list:
+        """Predictor._error of every candidate row (predict.py:475-509), as Python floats."""
+        cand = np.asarray(candidates, dtype=np.float64).reshape(-1, 6)
+        err, _, _, _ = self.engine.eval(cand, n_render, LOSS_FULL)
+        self.evaluations += len(cand)
+        return [float(e) for e in err]
+
+    # ------------------------------------------------------------------ the state machine
+    def run(self, target_color, target_depth, camera_pose=None):
+        if camera_pose is not None and np.any(np.asarray(camera_pose) != self.camera_pose):
+            self.changeCameraPose(camera_pose)
+
+        target_depth = self._downsample(np.asarray(target_depth), self.ds_factor)
+        if target_depth.dtype != np.float64:
+            target_depth = target_depth.astype(np.float64)
+        if self.synthetic:
+            self._loadSynthetic(target_color, target_depth)
+        else:
+            self._segmentLoad(target_color, target_depth)
+
+        limits = self.u_reader.joint_limits
+        lr = np.ones(6) * 0.1
+        history = np.zeros((self.history_length, 6))
+        err_history = np.zeros(self.history_length)
+        angles = np.array([0] * 6, dtype=float)
+        self._setStages()
+        self.trace = []
+
+        for stage in self.stages:
+            if type(stage) is Lookup:
+                angles = self._stage_lookup()
+            elif type(stage) is Descent:
+                angles, lr = self._stage_descent(stage, angles, lr, history, err_history, limits)
+            elif type(stage) is SFlip:
+                angles = self._stage_sflip(stage, angles, limits)
+            elif type(stage) is InterpolativeSweep:
+                angles = self._stage_isweep(stage, angles, history, err_history, limits)
+            elif type(stage) is TensorSweep:
+                angles = self._stage_tsweep(stage, angles, limits)
+            self.trace.append((type(stage).__name__, np.array(angles, dtype=float)))
+        return angles
+
+    def _stage_lookup(self):
+        """argmin over the pose grid of mean|T - sqrt(D_k)| * std|T - sqrt(D_k)| on the crop, T not
+        sqrt-ed (predict.py:165-171).  The grid is rendered and scored on the device."""
+        _, _, best, _ = self.engine.eval(self.lookup_angles, LOOKUP_NUM_RENDERED, LOSS_LOOKUP, crop=self.lookup_crop)
+        self.evaluations += len(self.lookup_angles)
+        return self.lookup_angles[best]
+
+    def _stage_descent(self, stage, angles, lr, history, err_history, limits):
+        for i in range(6):                                         # predict.py:175-177
+            if stage.init_rate[i] is not None:
+                lr[i] = stage.init_rate[i]
+        n = stage.to_render
+        over_err = under_err = np.inf
+        with np.errstate(all='ignore'):
+            for _ in range(stage.its):
+                for idx in np.where(stage.joints)[0]:
+                    if abs(np.mean(history, 0)[idx] - angles[idx]) <= lr[idx]:
+                        lr[idx] *= stage.rate_redux
+                    lr = np.max((lr, self.min_ang_inc), 0)
+
+                    under = angles.copy()
+                    under[idx] -= lr[idx]
+                    over = under.copy()
+                    over[idx] += 2 * lr[idx]
+                    ok_u = limits[idx][0] <= under[idx] <= limits[idx][1]
+                    ok_o = limits[idx][0] <= over[idx] <= limits[idx][1]
+                    batch = [c for c, ok in ((under, ok_u), (over, ok_o)) if ok]
+                    errs = self._errors(n, np.array(batch)) if batch else []
+                    under_err = errs.pop(0) if ok_u else np.inf
+                    over_err = errs.pop(0) if ok_o else np.inf
+
+                    if over_err < under_err:                        # ties and NaN: stay (predict.py:212-215)
+                        angles[idx] += lr[idx]
+                    elif over_err > under_err:
+                        angles[idx] -= lr[idx]
+
+                history[1:] = history[:-1]
+                history[0] = angles
+                err_history[1:] = err_history[:-1]
+                err_history[0] = min(over_err, under_err)           # of the LAST joint only (predict.py:222)
+                if abs(np.mean(err_history) - err_history[0]) / err_history[0] < stage.early_stop:
+                    break
+                spread = history.max(0) - history.min(0)
+                if ((spread <= self.min_ang_inc) + np.isclose(spread, self.min_ang_inc)).all():
+                    break
+                if (history[:3] == history[0]).all():
+                    break
+        return angles, lr
+
+    def _stage_sflip(self, stage, angles, limits):
+        n = stage.to_render
+        base_err = self._errors(n, angles)[0]
+        temp = angles.copy()
+        cam = self.camera_pose
+        a = cam[5] * np.abs(np.cos(cam[3])) + cam[4] * np.abs(np.sin(cam[3]))     # predict.py:245
+        temp[0] = -temp[0] + 2 * a * np.sign(temp[0])
+        limit_thresh = 0.15
+        close_to_limits = limit_thresh > abs(limits[0, 0] - temp[0]) or limit_thresh > abs(limits[0, 1] - temp[0])
+        in_limits = limits[0, 0] <= temp[0] <= limits[0, 1]
+        if in_limits:
+            err = self._errors(n, temp)[0]
+            if err < base_err:
+                angles = temp                                       # alias, as predict.py:261
+                base_err = err
+        if not in_limits or close_to_limits:
+            # predict.py:270-277: both endpoints are written into temp, but the comparison sits after
+            # the loop, so only the upper limit's error is ever used — and when the flip above was
+            # accepted, `angles` IS `temp`, so angles[0] becomes the upper limit regardless.
+            temp[0] = limits[0][1]
+            err = self._errors(n, temp)[0]
+            if err < base_err:
+                angles = temp
+                base_err = err
+        return angles
+
+    def _sweep_space(self, stage, angles, idx, limits):
+        lo, hi = angles.copy(), angles.copy()
+        if stage.range is None:
+            lo[idx], hi[idx] = limits[idx, 0], limits[idx, 1]
+        else:
+            lo[idx] = max(lo[idx] - stage.range, limits[idx, 0])
+            hi[idx] = min(hi[idx] + stage.range, limits[idx, 1])
+        return lo, hi, np.linspace(lo, hi, stage.divs)
+
+    def _stage_isweep(self, stage, angles, history, err_history, limits):
+        n, div = stage.to_render, stage.divs
+        base_err = self._errors(n, angles)[0]                       # not refreshed between joints (predict.py:288-289)
+        for idx in np.where(stage.joints)[0]:
+            lo, hi, space = self._sweep_space(stage, angles, idx, limits)
+            space_err = self._errors(n, space)
+            x = np.linspace(lo[idx], hi[idx], div * 5)
+            with np.errstate(all='ignore'):
+                predicted = cubic_interp(space[:, idx], np.array(space_err), x)
+            angs = angles.copy()
+            angs[idx] = x[predicted.argmin()]
+            pred_min_err = self._errors(n, angs)[0]
+
+            errs = [base_err, min(space_err), pred_min_err]
+            min_type = errs.index(min(errs))                        # ties go to the earlier entry
+            if min_type == 1:
+                angles = space[space_err.index(min(space_err))]
+                err_history[1:] = err_history[:-1]
+                err_history[0] = min(space_err)
+            elif min_type == 2:
+                angles = angs
+                err_history[1:] = err_history[:-1]
+                err_history[0] = pred_min_err
+            history[1:] = history[:-1]
+            history[0] = angles
+        return angles
+
+    def _stage_tsweep(self, stage, angles, limits):
+        """TensorSweep (predict.py:340-373): whole frame, sqrt of both depths, and the `*-` typo that
+        turns the score into mean * -std, so argmin picks the LARGEST mean*std."""
+        n = stage.to_render
+        full = np.ascontiguousarray(self._tgt_depth, dtype=np.float32)
+        self.engine.set_target(self._tq, full, self._flags)
+        try:
+            for idx in np.where(stage.joints)[0]:
+                _, _, space = self._sweep_space(stage, angles, idx, limits)
+                _, _, best, _ = self.engine.eval(space, n, LOSS_TSWEEP)
+                self.evaluations += len(space)
+                angles = space[best]
+        finally:
+            self.engine.set_target(self._tq, self._lookup_depth_f32, self._flags)
+        return angles

@@ -1,0 +1,65 @@
+"""GPU: the batched Predictor against the oracle's sequential restatement, decision by decision."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import predictor_ref
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, LINK_BLUE
+from rope_s3d_amd.crop import Crop, crop_pose_grid
+from rope_s3d_amd.imgproc import resize_linear
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+THREADS = min(os.cpu_count() or 1, 16)
+
+
+@pytest.fixture(scope='module')
+def synth():
+    from rope_s3d_amd import SyntheticPredictor
+    # 640x480 frames, predicted at 160x120 (ds_factor 4), 4^3 lookup grid: small enough for the CPU oracle
+    return SyntheticPredictor(DEFAULT_CAMERA_POSE, '640_480_color', 4, 'SLU', noise=False, seed=11, lookup_divisions=4)
+
+
+def test_crop_matches_oracle(synth):
+    p = synth.predictor
+    rb = helpers.robot()
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    o = helpers.make_oracle(rb, intr, PV)
+    crop = Crop(DEFAULT_CAMERA_POSE, intr, renderer=p.renderer, use_disk_cache=False)
+    for n in (1, 4, 6):
+        angles = np.zeros((1, 6)) if n == 1 else crop_pose_grid(rb.joint_limits, intr.size, n)[0]
+        cover = o.coverage(angles, n, threads=THREADS) != 0
+        r, c = np.where(cover)
+        want = [max(r.min() - 10, 0), min(r.max() + 10, intr.height - 1), max(c.min() - 10, 0), min(c.max() + 10, intr.width - 1)]
+        assert list(crop[n]) == want
+    assert list(crop[0]) == list(crop[6])
+
+
+@pytest.mark.parametrize('seed', [7919, 7920, 7921])
+def test_predictor_trace_matches_sequential_reference(synth, seed):
+    p = synth.predictor
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    q_true = np.random.default_rng(seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    synth.renderer.setJointAngles(q_true)
+    color, depth = synth.renderer.render()
+    got = p.run(color, depth)
+
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    o = helpers.make_oracle(rb, intr, PV)
+    tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+    tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+    names = rb.link_names
+    link_blue = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    want, trace, n_eval = predictor_ref.predict_reference(
+        o, tgt_depth, tgt_blue, names, link_blue, lim, DEFAULT_CAMERA_POSE,
+        helpers.slu_grid(lim, 4), p.lookup_crop, 'SLU')
+    assert len(trace) == len(p.trace)
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
+    # the synthetic pose is recovered to within the descent's terminal resolution
+    assert np.abs(got - q_true)[:3].max() < 0.25     # 4^3 lookup grid: coarse start, sanity bound only
