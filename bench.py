@@ -42,10 +42,21 @@ def slu_grid(limits, d):
     return ang
 
 
+def measured_traffic():
+    """HBM bytes per raster launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/summarize_prof.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE); null if absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            return json.load(f)['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample):
     """The CPU oracle (C restatement of the reference path) on this host's cores, bounded sample."""
     from oracle import oracle as orc
-    threads = os.cpu_count() or 1
+    # the GPU box exposes every host core but a 1-GPU job's share is 16 (gpurun process guard)
+    threads = min(len(os.sched_getaffinity(0)), 16)
     o = orc.Oracle(robot.verts, robot.faces, robot.vtx_off, robot.tri_off, robot.joint_fixed, robot.joint_axes,
                    PV, W, H, znear, zfar)
     sample = np.ascontiguousarray(cand[:n_sample])
@@ -140,14 +151,14 @@ def main():
             "metric": "rendered+scored candidate poses/sec @640x480",
             "value": poses / dt, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i64 edge functions / f64 depth interpolation / f32 linear depth / u64 Q32 sums",
+            "vs_baseline": None, "dtype": "i32/i64 fixed-point edge functions, f32 depth, u64 Q32 sums",
             "data": "synthetic",
             "config": {"workload": "configs[1]: mh5l_limited URDF, 640x480, 4096 candidates/frame (16^3 SLU grid), "
                                    "depth-only loss, 6 links, one frame per rank",
                        "candidates_per_step": C, "frames_per_rank": 1, "parallelism": f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "raster_score_kernel<DEPTH,SCORE>", "kernel_ms": kern['raster'],
                          "bytes_per_candidate": B_CAND, "candidates_per_launch": C,
                          "other_kernels_ms": {"fk_mvp": kern['fk'], "finalize+argmin": kern['finalize'],

@@ -82,7 +82,9 @@ def predict_reference(o: orc.Oracle, tgt_depth, tgt_blue, link_names, link_blue,
                     key = o.raster_key(a, 6)
                     score[i] = o.finalize(o.sums(key, orc.LOSS_LOOKUP, 6, None, t_lookup, crop), orc.LOSS_LOOKUP, 6, npx, flags)
                 count[0] += len(lookup_angles)
-                angles = lookup_angles[int(np.argmin(score))]
+                # copy: the reference keeps a view and later mutates its table in place (a cross-frame state leak
+                # that is deliberately not restated; the first frame of a fresh Predictor is unaffected)
+                angles = np.array(lookup_angles[int(np.argmin(score))], dtype=float)
 
             elif kind == 'descent':                    # predict.py:173-230
                 _, n, its, letters, init_rate, redux, early = st

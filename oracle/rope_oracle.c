@@ -17,7 +17,8 @@
  *   mvp             pyrender P·V·M              robotpose/simulation/render.py:52-60,88-90
  *   raster          pyrender SEG offscreen pass robotpose/simulation/render.py:92-98
  *                   (GL rules: pixel-centre sampling, top-left fill, GL_LESS on a
- *                   24-bit window depth, back-face culling, znear .05 / zfar 100)
+ *                   24-bit window depth interpolated as a float32 plane in screen
+ *                   space, back-face culling, znear .05 / zfar 100)
  *   resolve         pyrender depth read-back    z = 2nf/(f+n-(2d-1)(f-n)), d==1 -> 0, f32 ops
  *   sums/finalize   Predictor._error            robotpose/prediction/predict.py:475-509
  *                   Lookup score                robotpose/prediction/predict.py:165-171

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Predict every frame of a dataset (same command line as the reference's predict_dataset.py:58-64).
+
+    python predict_dataset.py <dataset> [-angs SLU]
+    python -m torch.distributed.run --nproc-per-node N ... predict_dataset.py <dataset>    # frames shard over N GPUs
+
+Frames are independent, so rank r predicts a contiguous block of frames on its own GPU and
+the only communication is one all-gather of the (n, 6) float64 results (RCCL over xGMI).
+Output: predictions_<dataset>.npy, as the reference (predict_dataset.py:47-49).
+"""
+import argparse
+import os
+
+import numpy as np
+
+from robotpose import Dataset, Grapher, Predictor
+from rope_s3d_amd.parallel import dist_env, gather_rows, shard_range
+
+
+def run(args):
+    rank, world, local_rank = dist_env()
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+            device = torch.device('cuda', local_rank)
+        dist.init_process_group('nccl' if use_gpu else 'gloo', device_id=device)
+
+    ds = Dataset(args.dataset)
+    kwargs = {}
+    if ds.attrs.get('synthetic'):
+        kwargs['color_dict'] = ds.attrs['color_dict']         # link masks are read from the colour render
+    am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
+                   do_angles=args.angs, model_ds=args.dataset, device=local_rank, **kwargs)
+
+    lo, hi = shard_range(ds.length, rank, world)
+    out = np.zeros((hi - lo, 6))
+    chunk = 200                                                 # the reference reads ~200 frames at a time (predict_dataset.py:27-41)
+    for start in range(lo, hi, chunk):
+        end = min(start + chunk, hi)
+        og_imgs = np.copy(ds.og_img[start:end])
+        dms = np.copy(ds.depthmaps[start:end])
+        cam_poses = np.copy(ds.camera_pose[start:end])
+        for i in range(end - start):
+            out[start - lo + i] = am.run(og_imgs[i], dms[i], cam_poses[i])
+    full = gather_rows(out, ds.length, device=device)
+    if rank == 0:
+        np.save(f'predictions_{os.path.basename(os.path.normpath(args.dataset))}.npy', full)
+        Grapher(args.angs, full, np.copy(ds.angles)).plot()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return full
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument('dataset', type=str, help="The dataset to predict on.")
+    parser.add_argument('-angs', type=str, default='SLU', help="The joints to predict.")
+    parser.add_argument('-ds_factor', type=int, default=8, help="Downsampling factor (the reference hard-codes 8).")
+    run(parser.parse_args())

@@ -255,7 +255,10 @@ class Predictor:
         sqrt-ed (predict.py:165-171).  The grid is rendered and scored on the device."""
         _, _, best, _ = self.engine.eval(self.lookup_angles, LOOKUP_NUM_RENDERED, LOSS_LOOKUP, crop=self.lookup_crop)
         self.evaluations += len(self.lookup_angles)
-        return self.lookup_angles[best]
+        # .copy(): the reference returns a row VIEW of its angle table (predict.py:171), which the Descent
+        # stage then edits in place (predict.py:213), so its table drifts from frame to frame.  Frames stay
+        # independent here (DESIGN.md §6, deliberate deviation); on a fresh Predictor both agree.
+        return self.lookup_angles[best].copy()
 
     def _stage_descent(self, stage, angles, lr, history, err_history, limits):
         for i in range(6):                                         # predict.py:175-177

@@ -1,0 +1,44 @@
+"""world_size-2 run of the frame sharding + the single gather, on CPU with gloo."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from rope_s3d_amd.parallel import shard_range, gather_rows, dist_env
+    rank, world, _ = dist_env()
+    dist.init_process_group('gloo')
+    n = 11
+    lo, hi = shard_range(n, rank, world)
+    # stand-in for per-frame predictions: row f = f * [1..6]
+    local = np.arange(lo, hi)[:, None] * np.arange(1, 7)[None, :].astype(np.float64)
+    full = gather_rows(local, n)
+    assert full.shape == (n, 6), full.shape
+    assert np.array_equal(full, np.arange(n)[:, None] * np.arange(1, 7)[None, :])
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(%r, 'rank%%d.txt' %% rank), 'w').write('%%d %%d' %% (lo, hi))
+""")
+
+
+def test_two_rank_shard_and_gather(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % (ROOT, str(tmp_path)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / 'rank0.txt').read_text() == '0 6' and (tmp_path / 'rank1.txt').read_text() == '6 11'

