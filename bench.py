@@ -75,7 +75,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--grid', type=int, default=16, help='S/L/U divisions per joint (16 -> 4096 candidates)')
-    ap.add_argument('--cpu-sample', type=int, default=2048)
+    ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -161,7 +161,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "raster_score_kernel<DEPTH,SCORE>", "kernel_ms": kern['raster'],
                          "bytes_per_candidate": B_CAND, "candidates_per_launch": C,
-                         "other_kernels_ms": {"fk_mvp": kern['fk'], "finalize+argmin": kern['finalize'],
+                         "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
                                               "pass_total": kern['total']}},
         }
         if not args.no_cpu_baseline:

@@ -107,7 +107,8 @@ int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);
 int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop, int reps, float *ms);
 
 /* Profiling aid, never used by the product path: bit mask of kernel phases to skip
- * (1 meshlet culling onward, 2 vertex shading onward, 4 triangle set-up, 8 pixel loop, 16 loss pass).
+ * (1 meshlet culling onward, 2 vertex shading onward, 4 triangle set-up, 8 pixel loop, 16 loss pass,
+ * 32 small-triangle loops, 64 row pass, 128 disables shared upstream layers — results stay exact for 128).
  * Results are meaningless while a bit is set. */
 int rope_debug_skip(rope_ctx *ctx, int mask);
 

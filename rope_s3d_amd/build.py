@@ -20,15 +20,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(_CSRC, d)) > t for d in _DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, out_name: str = 'librope_hip.so') -> str:
+    if not force and not needs_build() and out_name == 'librope_hip.so':
         return LIB_PATH
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    cmd = [hipcc] + HIPCC_FLAGS + _SOURCES + ['-o', 'librope_hip.so']
+    extra = os.environ.get('ROPE_HIPCC_EXTRA', '').split()      # experiments only, e.g. -DROPE_SMALL_TRI_PIXELS=8
+    cmd = [hipcc] + HIPCC_FLAGS + extra + _SOURCES + ['-o', out_name]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
-    return LIB_PATH
+    return os.path.join(_CSRC, out_name)
 
 
 if __name__ == '__main__':

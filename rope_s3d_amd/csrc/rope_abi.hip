@@ -2,6 +2,7 @@
 // Declarations and the reference call sites each entry point replaces: include/rope_s3d.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -21,7 +22,7 @@ struct rope_ctx {
     bool have_robot = false;
     RobotParams rp{};
     uint32_t *d_header = nullptr, *d_tris = nullptr;
-    float *d_verts = nullptr;
+    float *d_verts = nullptr, *d_aabb = nullptr;
     double *d_joint_fixed = nullptr, *d_joint_axes = nullptr;
     int n_links = 0, n_meshlets = 0;
 
@@ -47,7 +48,16 @@ struct rope_ctx {
     // candidates + results
     int C = 0, cap = 0;
     double *d_cand = nullptr, *d_err = nullptr, *d_best_err = nullptr;
-    float *d_mvp = nullptr, *d_scale = nullptr;
+    float *d_mvp = nullptr;
+    short4 *d_bounds = nullptr;
+    uint32_t *d_mask_lo = nullptr, *d_mask_hi = nullptr;
+    int mask_words = 0;
+    // shared upstream layers: candidates with bit-identical (q0, q1) have identical links 0..2
+    int n_layers = 0;
+    int32_t *d_layer_of = nullptr, *d_layer_rep = nullptr;
+    uint32_t *d_layers = nullptr;
+    size_t layers_cap = 0;                 // keys allocated in d_layers
+    int layer_rep_cap = 0;
     uint64_t *d_sums = nullptr;
     int32_t *d_best_idx = nullptr;
     int last_n_render = 0;
@@ -118,7 +128,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_scale, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -139,7 +149,7 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
     if (n_meshlets < 1 || n_meshlets > MAX_MESHLETS) ARG_FAIL(c, "rope_set_robot: meshlet count out of range");
     if (link_first[0] != 0 || link_first[n_links] != n_meshlets) ARG_FAIL(c, "rope_set_robot: link_first does not span the meshlets");
     // validate every meshlet against the pools so that no kernel can index out of bounds
-    std::vector<double> lo(3 * n_links, 1e30), hi(3 * n_links, -1e30);
+    std::vector<float> aabb(8 * (size_t)n_meshlets, 0.0f);
     for (int l = 0; l < n_links; l++) {
         if (link_first[l + 1] < link_first[l]) ARG_FAIL(c, "rope_set_robot: link_first not monotone");
         for (int m = link_first[l]; m < link_first[l + 1]; m++) {
@@ -152,13 +162,21 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
                 uint32_t p = ml_tris[t0 + t];
                 if ((p & 0xFF) >= nv || ((p >> 8) & 0xFF) >= nv || ((p >> 16) & 0xFF) >= nv) ARG_FAIL(c, "rope_set_robot: triangle index outside its meshlet");
             }
+            double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
             for (uint32_t v = 0; v < nv; v++)
                 for (int k = 0; k < 3; k++) {
                     double x = ml_verts[3 * (size_t)(v0 + v) + k];
                     if (!std::isfinite(x)) ARG_FAIL(c, "rope_set_robot: non-finite vertex");
-                    lo[3 * l + k] = std::min(lo[3 * l + k], x);
-                    hi[3 * l + k] = std::max(hi[3 * l + k], x);
+                    lo[k] = std::min(lo[k], x);
+                    hi[k] = std::max(hi[k], x);
                 }
+            for (int k = 0; k < 3; k++) {
+                // box centre and half extent, rounded outwards
+                float ctr = (float)(0.5 * (lo[k] + hi[k]));
+                float ext = (float)(std::max(hi[k] - (double)ctr, (double)ctr - lo[k]) * (1.0 + 1e-6) + 1e-7);
+                aabb[8 * (size_t)m + k] = ctr;
+                aabb[8 * (size_t)m + 4 + k] = ext;
+            }
         }
     }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -166,6 +184,8 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
     HIP_TRY(c, realloc_dev(&c->d_header, 8 * (size_t)n_meshlets));
     HIP_TRY(c, realloc_dev(&c->d_verts, 3 * (size_t)n_ml_verts));
     HIP_TRY(c, realloc_dev(&c->d_tris, (size_t)n_ml_tris));
+    HIP_TRY(c, realloc_dev(&c->d_aabb, 8 * (size_t)n_meshlets));
+    HIP_TRY(c, hipMemcpy(c->d_aabb, aabb.data(), 32 * (size_t)n_meshlets, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_header, ml_header, 32 * (size_t)n_meshlets, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_verts, ml_verts, 12 * (size_t)n_ml_verts, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tris, ml_tris, 4 * (size_t)n_ml_tris, hipMemcpyHostToDevice));
@@ -175,15 +195,10 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
     c->rp.ml_verts = c->d_verts;
     c->rp.ml_tris = c->d_tris;
     for (int l = 0; l <= ROPE_MAX_LINKS; l++) c->rp.link_first[l] = link_first[l < n_links ? l : n_links];
-    for (int l = 0; l < ROPE_MAX_LINKS; l++) {
-        float *b = c->rp.link_bound + 4 * l;
-        b[0] = b[1] = b[2] = b[3] = 0.0f;
-        if (l >= n_links || link_first[l + 1] == link_first[l]) continue;
-        double cx = 0.5 * (lo[3 * l] + hi[3 * l]), cy = 0.5 * (lo[3 * l + 1] + hi[3 * l + 1]), cz = 0.5 * (lo[3 * l + 2] + hi[3 * l + 2]);
-        double dx = hi[3 * l] - cx, dy = hi[3 * l + 1] - cy, dz = hi[3 * l + 2] - cz;
-        b[0] = (float)cx; b[1] = (float)cy; b[2] = (float)cz;
-        b[3] = (float)(std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001 + 1e-6);
-    }
+    c->rp.ml_aabb = c->d_aabb;
+    c->rp.n_meshlets = n_meshlets;
+    c->cap = 0;                                   // per-candidate buffers depend on the meshlet count
+    c->C = 0;
     c->n_links = n_links;
     c->n_meshlets = n_meshlets;
     c->have_robot = true;
@@ -207,6 +222,8 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
     c->fp.c_sum = (float)(zfar + znear);
     c->fp.c_dif = (float)(zfar - znear);
     c->n_tiles = c->fp.tiles_x * c->fp.tiles_y;
+    if ((c->n_tiles + 31) / 32 > MAX_MASK_WORDS) ARG_FAIL(c, "rope_set_camera: too many tiles");
+    if ((c->n_tiles + 31) / 32 != c->mask_words) { c->mask_words = (c->n_tiles + 31) / 32; c->cap = 0; c->C = 0; }
     HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
     if (resized) {
         size_t n = (size_t)W * H;
@@ -252,7 +269,11 @@ static int ensure_capacity(rope_ctx *c, int C)
     HIP_TRY(c, realloc_dev(&c->d_cand, 6 * (size_t)cap));
     HIP_TRY(c, realloc_dev(&c->d_err, (size_t)cap));
     HIP_TRY(c, realloc_dev(&c->d_mvp, (size_t)cap * ROPE_MAX_LINKS * 16));
-    HIP_TRY(c, realloc_dev(&c->d_scale, (size_t)cap * ROPE_MAX_LINKS * 4));
+    if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "candidates: robot and camera must be set first");
+    HIP_TRY(c, realloc_dev(&c->d_bounds, (size_t)cap * c->n_meshlets));
+    HIP_TRY(c, realloc_dev(&c->d_mask_lo, (size_t)cap * c->mask_words));
+    HIP_TRY(c, realloc_dev(&c->d_mask_hi, (size_t)cap * c->mask_words));
+    HIP_TRY(c, realloc_dev(&c->d_layer_of, (size_t)cap));
     HIP_TRY(c, realloc_dev(&c->d_sums, (size_t)cap * ROPE_SUM_WORDS));
     c->cap = cap;
     return ROPE_OK;
@@ -268,7 +289,30 @@ extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
     int rc = ensure_capacity(c, C);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_cand, cand, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
+    // group candidates whose first two joint angles are bit-identical: their base_link, link_1_s and
+    // link_2_l transforms are the same bits, so those links are rasterised once per group (a "layer")
+    struct Key { uint64_t a, b; int idx; };
+    std::vector<Key> keys((size_t)C);
+    for (int i = 0; i < C; i++) {
+        std::memcpy(&keys[i].a, &cand[6 * (size_t)i], 8);
+        std::memcpy(&keys[i].b, &cand[6 * (size_t)i + 1], 8);
+        keys[i].idx = i;
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.idx < y.idx); });
+    std::vector<int32_t> layer_of((size_t)C), layer_rep;
+    for (int i = 0; i < C; i++) {
+        if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) layer_rep.push_back(keys[i].idx);
+        layer_of[keys[i].idx] = (int32_t)layer_rep.size() - 1;
+    }
+    c->n_layers = (int)layer_rep.size();
+    if (c->n_layers > c->layer_rep_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, realloc_dev(&c->d_layer_rep, (size_t)c->n_layers));
+        c->layer_rep_cap = c->n_layers;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_layer_of, layer_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_layer_rep, layer_rep.data(), layer_rep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller
     c->C = C;
     return ROPE_OK;
 }
@@ -302,15 +346,48 @@ static int ensure_empty(rope_ctx *c, int loss, const FrameParams &fp)
     return ROPE_OK;
 }
 
+// Layers pay off when many candidates share one upstream pose (lookup grids, sweeps of U).
+static bool want_layers(const rope_ctx *c) { return c->n_layers * 4 <= c->C; }
+
+static int ensure_layers(rope_ctx *c)
+{
+    size_t need = (size_t)c->n_layers * c->n_tiles * (TILE_W * TILE_H);
+    if (need <= c->layers_cap) return ROPE_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, realloc_dev(&c->d_layers, need));
+    c->layers_cap = need;
+    return ROPE_OK;
+}
+
+static RasterArgs base_args(rope_ctx *c, int n_render)
+{
+    RasterArgs a{};
+    a.l_begin = 0; a.l_end = n_render; a.n_render = n_render;
+    a.mvp = c->d_mvp; a.bounds = c->d_bounds;
+    a.mask_lo = c->d_mask_lo; a.mask_hi = c->d_mask_hi; a.mask_words = c->mask_words;
+    return a;
+}
+
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
                         hipEvent_t *ev /* 4 events or nullptr */)
 {
+    const bool layers = want_layers(c) && !(fp.debug & 128);
+    const int n_shared = layers ? std::min(3, n_render) : 0;
+    if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_scale));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp));
+    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, (size_t)c->C * ROPE_SUM_WORDS * sizeof(uint64_t), c->stream));
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-    HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, n_render, c->d_mvp, c->d_scale, c->d_tq,
-                             c->d_t32, c->d_empty[loss], c->d_sums, nullptr, nullptr));
+    RasterArgs a = base_args(c, n_render);
+    if (layers) {
+        RasterArgs la = a;
+        la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
+        HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
+        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers;
+    }
+    a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss]; a.sums = c->d_sums;
+    HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err,
                                c->d_best_idx, c->d_best_err));
@@ -368,9 +445,11 @@ static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "render: n_render out of range");
     int rc = rope_candidates_upload(c, cand, C);
     if (rc) return rc;
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_scale));
-    HIP_TRY(c, launch_raster(mode, ROPE_LOSS_DEPTH, c->C, c->stream, c->fp, c->rp, n_render, c->d_mvp, c->d_scale,
-                             nullptr, nullptr, nullptr, nullptr, c->d_key, c->d_cover));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp));
+    HIP_TRY(c, launch_bounds(c->stream, c->C, c->fp, c->rp, n_render, 0, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    RasterArgs a = base_args(c, n_render);
+    a.key_out = c->d_key; a.cover = c->d_cover;
+    HIP_TRY(c, launch_raster(mode, ROPE_LOSS_DEPTH, c->C, c->stream, c->fp, c->rp, a));
     c->last_n_render = n_render;
     return ROPE_OK;
 }

@@ -11,9 +11,13 @@ constexpr int TILE_W = 128;
 constexpr int TILE_H = 64;
 constexpr int NWAVES = 8;                 // waves per workgroup of the raster kernel
 constexpr int NTHREADS = NWAVES * 64;
-constexpr int SMALL_TRI_PIXELS = 16;      // bounding boxes up to this many samples are walked by one lane
+#ifndef ROPE_SMALL_TRI_PIXELS
+#define ROPE_SMALL_TRI_PIXELS 16
+#endif
+constexpr int SMALL_TRI_PIXELS = ROPE_SMALL_TRI_PIXELS;   // bounding boxes up to this many samples are walked by one lane
 constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet list in LDS
 constexpr int MESHLET_MAX_VERTS = 128;
+constexpr int MAX_MASK_WORDS = 256;        // tile-mask words per candidate (8192 tiles)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t D24_MAX = 16777215u;
 
@@ -21,7 +25,7 @@ constexpr uint32_t D24_MAX = 16777215u;
 enum { SUM_CNT = 0, SUM_S1 = 1, SUM_AA = 2, SUM_AB = 3, SUM_BB = 4, SUM_LINK0 = 5 };
 static_assert(SUM_LINK0 + 3 * ROPE_MAX_LINKS == ROPE_SUM_WORDS, "sum layout");
 
-enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2 };
+enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3 };
 
 struct FrameParams {
     int W, H, tiles_x, tiles_y;
@@ -34,17 +38,36 @@ struct RobotParams {
     const uint32_t *ml_header;            // n_meshlets x 8
     const float *ml_verts;                // x3
     const uint32_t *ml_tris;
+    const float *ml_aabb;                 // n_meshlets x 8: box centre xyz,0 and half extents xyz,0 (link frame)
     int link_first[ROPE_MAX_LINKS + 1];
-    float link_bound[ROPE_MAX_LINKS * 4]; // bounding sphere of every link (link frame)
+    int n_meshlets;
 };
 
 struct LinkFlags { uint8_t f[8]; };
 
+// Arguments of one raster launch.  Grid = (tiles, rows); a row is a candidate, or in MODE_LAYER a
+// shared layer (links [0, n_shared) of all candidates with the same first two joint angles).
+struct RasterArgs {
+    int l_begin, l_end;                   // links rasterised by this launch
+    int n_render;                         // links that count for the loss terms
+    const float *mvp;                     // C x 6 x 16
+    const short4 *bounds;                 // C x n_meshlets screen boxes
+    const uint32_t *mask_lo, *mask_hi;    // C x mask_words: tiles touched by links < n_shared / >= n_shared
+    int mask_words;
+    const int32_t *cand_of_row;           // MODE_LAYER: layer -> representative candidate; else nullptr
+    const int32_t *layer_of;              // candidate -> layer, nullptr when layers are not in use
+    uint32_t *layers;                     // n_layers x n_tiles x (TILE_W*TILE_H) keys
+    const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
+    uint64_t *sums; uint32_t *key_out; uint8_t *cover;
+};
+
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
-                     const double *joint_axes, const double *PV, float *mvp, float *scale);
-hipError_t launch_raster(int mode, int loss, int C, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                         int n_render, const float *mvp, const float *scale, const uint64_t *tq, const float *t32,
-                         const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out, uint8_t *cover);
+                     const double *joint_axes, const double *PV, float *mvp);
+// screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
+hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
+                         const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
+hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                         const RasterArgs &a);
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,
                         uint64_t *empty_sums, uint64_t *total);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,

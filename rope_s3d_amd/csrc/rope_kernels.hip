@@ -74,12 +74,10 @@ __device__ static inline void aff_mul(const double *A, const double *B, double *
     }
 }
 
-// One thread per candidate.  Writes n_render 4x4 float matrices plus, per link, the
-// clip-space scale of a unit sphere radius along x, y and w (for meshlet culling).
+// One thread per candidate.  Writes n_render 4x4 float matrices.
 __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
-              const double *__restrict__ joint_axes, const double *__restrict__ PV,
-              float *__restrict__ mvp, float *__restrict__ mvp_scale)
+              const double *__restrict__ joint_axes, const double *__restrict__ PV, float *__restrict__ mvp)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -102,23 +100,13 @@ fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double
             for (int k = 0; k < 12; k++) T[k] = N[k];
         }
         float *o = mvp + ((size_t)c * ROPE_MAX_LINKS + l) * 16;
-        float *sc = mvp_scale + ((size_t)c * ROPE_MAX_LINKS + l) * 4;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const double p0 = PV[4 * r], p1 = PV[4 * r + 1], p2 = PV[4 * r + 2], p3 = PV[4 * r + 3];
-            float m[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                m[k] = (float)((p0 * T[0 + k] + p1 * T[4 + k]) + p2 * T[8 + k]);
-                o[4 * r + k] = m[k];
-            }
+            for (int k = 0; k < 3; k++) o[4 * r + k] = (float)((p0 * T[0 + k] + p1 * T[4 + k]) + p2 * T[8 + k]);
             o[4 * r + 3] = (float)(((p0 * T[3] + p1 * T[7]) + p2 * T[11]) + p3);
-            if (r != 2) {
-                float nrm = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * 1.0001f;
-                sc[r == 3 ? 2 : r] = nrm;
-            }
         }
-        sc[3] = 0.0f;
     }
 }
 
@@ -269,26 +257,69 @@ __device__ static inline int64_t edge_fn(int32_t ax, int32_t ay, int32_t bx, int
     return (int64_t)(bx - ax) * (int64_t)(fy - ay) - (int64_t)(by - ay) * (int64_t)(fx - ax);
 }
 
-// Conservative screen-space test of a bounding sphere against a pixel rectangle
-// [px0,px1] x [py0,py1] (GL window coordinates, y up).  Only ever answers "no" when no
-// sample of the rectangle can be covered; it never changes results, only work.
-__device__ static inline bool sphere_hits_rect(const float *m, const float *sc, float x, float y, float z, float rad,
-                                               float hw, float hh, float px0, float px1, float py0, float py1)
+// Screen bounding box (GL window pixels, y up, inclusive) of every meshlet of every candidate, from the
+// eight corners of its link-frame box, plus per candidate a bit mask of the tiles any meshlet may touch.
+// Conservative by construction (1 px margin over rounding and sub-pixel snapping): it only ever removes
+// work that cannot produce a sample, never a sample.  Empty boxes are stored as x0 > x1.
+__global__ void __launch_bounds__(256)
+bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const float *__restrict__ mvp_all,
+              short4 *__restrict__ bounds, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words)
 {
-    float cx = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
-    float cy = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
-    float cw = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15])));
-    float rx = rad * sc[0], ry = rad * sc[1], rw = rad * sc[2];
-    float wlo = cw - rw, whi = cw + rw;
-    if (whi <= 0.0f) return false;                 // wholly behind the eye: every vertex has w <= 0
-    if (wlo <= 1e-6f) return true;                 // straddles the eye plane: cannot bound
-    float ilo = 1.0f / wlo, ihi = 1.0f / whi;
-    float xlo = cx - rx, xhi = cx + rx, ylo = cy - ry, yhi = cy + ry;
-    float nxlo = xlo < 0.0f ? xlo * ilo : xlo * ihi, nxhi = xhi > 0.0f ? xhi * ilo : xhi * ihi;
-    float nylo = ylo < 0.0f ? ylo * ilo : ylo * ihi, nyhi = yhi > 0.0f ? yhi * ilo : yhi * ihi;
-    float sxlo = fmaf(nxlo, hw, hw) - 1.5f, sxhi = fmaf(nxhi, hw, hw) + 1.5f;
-    float sylo = fmaf(nylo, hh, hh) - 1.5f, syhi = fmaf(nyhi, hh, hh) + 1.5f;
-    return !(sxhi < px0 || sxlo > px1 + 1.0f || syhi < py0 || sylo > py1 + 1.0f);
+    __shared__ uint32_t s_mask[2][MAX_MASK_WORDS];      // [0]: links < n_shared, [1]: the others
+    const int cand = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < mask_words; i += blockDim.x) s_mask[0][i] = s_mask[1][i] = 0;
+    __syncthreads();
+    if (m < rp.n_meshlets) {
+        short4 bb = make_short4(1, 0, 1, 0);
+        const int l = (int)rp.ml_header[8 * m + 7];
+        if (l < n_render) {
+            const float4 ctr = reinterpret_cast<const float4 *>(rp.ml_aabb)[2 * m];
+            const float4 ext = reinterpret_cast<const float4 *>(rp.ml_aabb)[2 * m + 1];
+            const float *mm = mvp_all + ((size_t)cand * ROPE_MAX_LINKS + l) * 16;
+            const float hw = 0.5f * (float)fp.W, hh = 0.5f * (float)fp.H;
+            float sxlo = 3.0e38f, sxhi = -3.0e38f, sylo = 3.0e38f, syhi = -3.0e38f;
+            bool behind = false, front = false;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float x = ctr.x + ((k & 1) ? ext.x : -ext.x), y = ctr.y + ((k & 2) ? ext.y : -ext.y),
+                            z = ctr.z + ((k & 4) ? ext.z : -ext.z);
+                const float cx = fmaf(mm[0], x, fmaf(mm[1], y, fmaf(mm[2], z, mm[3])));
+                const float cy = fmaf(mm[4], x, fmaf(mm[5], y, fmaf(mm[6], z, mm[7])));
+                const float cw = fmaf(mm[12], x, fmaf(mm[13], y, fmaf(mm[14], z, mm[15])));
+                if (cw <= 1e-4f) { behind = true; continue; }
+                front = true;
+                const float rw = 1.0f / cw;
+                const float sx = fmaf(cx * rw, hw, hw), sy = fmaf(cy * rw, hh, hh);
+                sxlo = fminf(sxlo, sx); sxhi = fmaxf(sxhi, sx);
+                sylo = fminf(sylo, sy); syhi = fmaxf(syhi, sy);
+            }
+            if (front) {
+                int x0, x1, y0, y1;
+                if (behind) { x0 = 0; x1 = fp.W - 1; y0 = 0; y1 = fp.H - 1; }   // straddles the eye plane: cannot bound
+                else {
+                    // sample centre p+0.5 inside [lo,hi] (+ margin)  <=>  p in [lo-1.5, hi+0.5]
+                    x0 = (int)fmaxf(floorf(sxlo - 1.5f), 0.0f); x1 = (int)fminf(ceilf(sxhi + 0.5f), (float)(fp.W - 1));
+                    y0 = (int)fmaxf(floorf(sylo - 1.5f), 0.0f); y1 = (int)fminf(ceilf(syhi + 0.5f), (float)(fp.H - 1));
+                }
+                if (x0 <= x1 && y0 <= y1) {
+                    bb = make_short4((short)x0, (short)x1, (short)y0, (short)y1);
+                    const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
+                    const int ty0 = (fp.H - 1 - y1) / TILE_H, ty1 = (fp.H - 1 - y0) / TILE_H;
+                    for (int ty = ty0; ty <= ty1; ty++)
+                        for (int tx = tx0; tx <= tx1; tx++) {
+                            const int t = ty * fp.tiles_x + tx;
+                            atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
+                        }
+                }
+            }
+        }
+        bounds[(size_t)cand * rp.n_meshlets + m] = bb;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < mask_words; i += blockDim.x) {
+        if (s_mask[0][i]) atomicOr(&mask_lo[(size_t)cand * mask_words + i], s_mask[0][i]);
+        if (s_mask[1][i]) atomicOr(&mask_hi[(size_t)cand * mask_words + i], s_mask[1][i]);
+    }
 }
 
 // Tile frame: u = px - col0 in [0,TILE_W), v = py - vy0 in [0,TILE_H) with py the GL window
@@ -387,14 +418,13 @@ struct QEntry { uint32_t packed; float gx, gy, dc; };   // queued triangle: vert
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
 template <int LOSS, int MODE>
 __global__ void __launch_bounds__(NTHREADS)
-raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *__restrict__ mvp_all,
-                    const float *__restrict__ scale_all, const uint64_t *__restrict__ tq,
-                    const float *__restrict__ t32, const uint64_t *__restrict__ empty_sums,
-                    uint64_t *__restrict__ sums, uint32_t *__restrict__ key_out, uint8_t *__restrict__ cover)
+raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 {
+    const int n_render = ra.n_render;
+    const uint64_t *__restrict__ tq = ra.tq;
+    const float *__restrict__ t32 = ra.t32;
     __shared__ uint32_t tile[TILE_W * TILE_H];
     __shared__ float s_mvp[ROPE_MAX_LINKS * 16];
-    __shared__ float s_scale[ROPE_MAX_LINKS * 4];
     __shared__ uint16_t s_list[MAX_MESHLETS];
     __shared__ int s_count;
     __shared__ SVert s_vert[NWAVES][MESHLET_MAX_VERTS];
@@ -403,7 +433,8 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_id = blockIdx.x, cand = blockIdx.y;
+    const int tile_id = blockIdx.x;
+    const int cand = (MODE == MODE_LAYER) ? ra.cand_of_row[blockIdx.y] : (int)blockIdx.y;
     const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
     const int col0 = tx * TILE_W, row0 = ty * TILE_H;
     // tile rectangle in GL window pixel coordinates (y up), clamped to the image
@@ -416,41 +447,42 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
     tf.u1 = wx1 - col0;
     tf.v0 = wy0 - tf.vy0;
 
-    if (tid < n_render * 16) s_mvp[tid] = mvp_all[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
-    if (tid < n_render * 4) s_scale[tid] = scale_all[((size_t)cand * ROPE_MAX_LINKS) * 4 + tid];
+    // tiles no meshlet of this candidate can touch keep their "empty" sums: nothing to do
+    const size_t mw = (size_t)cand * ra.mask_words + (tile_id >> 5);
+    const bool hit_lo = (ra.mask_lo[mw] >> (tile_id & 31)) & 1u, hit_hi = (ra.mask_hi[mw] >> (tile_id & 31)) & 1u;
+    if (MODE == MODE_LAYER ? !hit_lo : !(hit_lo || hit_hi)) return;
+    if (fp.debug & 1) return;
+    // shared layer (links below l_begin, rendered once per distinct upstream pose) covering this tile
+    const uint32_t *layer_tile = nullptr;
+    if (MODE != MODE_LAYER && ra.layer_of && hit_lo)
+        layer_tile = ra.layers + ((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
+
+    if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
     if (tid == 0) s_count = 0;
     if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
     __syncthreads();
 
-    // --- meshlet culling: links first (6 spheres), then the meshlets of the links that hit
-    unsigned link_hit = 0;
-    for (int l = 0; l < n_render; l++) {
-        const float *b = rp.link_bound + 4 * l;
-        if (sphere_hits_rect(s_mvp + 16 * l, s_scale + 4 * l, b[0], b[1], b[2], b[3], hw, hh,
-                             (float)wx0, (float)wx1, (float)wy0, (float)wy1))
-            link_hit |= 1u << l;
-    }
-    if (!link_hit) return;                        // uniform: every thread tested the same six spheres
-    if (fp.debug & 1) return;
+    // --- meshlets whose screen box meets this tile
     {
-        const int m_end = rp.link_first[n_render];
-        for (int m = tid; m < m_end; m += NTHREADS) {
-            const uint4 h0 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m];
-            const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
-            const int l = (int)h1.w;
-            if (!((link_hit >> l) & 1)) continue;
-            if (sphere_hits_rect(s_mvp + 16 * l, s_scale + 4 * l, __uint_as_float(h0.x), __uint_as_float(h0.y),
-                                 __uint_as_float(h0.z), __uint_as_float(h0.w), hw, hh, (float)wx0, (float)wx1,
-                                 (float)wy0, (float)wy1)) {
+        const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
+        const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
+        for (int m = m_begin + tid; m < m_end; m += NTHREADS) {
+            const short4 b = bb[m];
+            if (b.x <= b.y && b.x <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
                 int pos = atomicAdd(&s_count, 1);
                 s_list[pos] = (uint16_t)m;
             }
         }
     }
-    for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
+    if (layer_tile) {
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
+            reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(layer_tile)[i];
+    } else {
+        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
+    }
     __syncthreads();
     const int n_list = s_count;
-    if (n_list == 0) return;                      // nothing can land in this tile: its sums stay "empty"
+    if (n_list == 0 && !layer_tile && MODE != MODE_LAYER) return;   // nothing lands in this tile: its sums stay "empty"
 
     // --- one meshlet per wave at a time
     SVert *const wv = s_vert[wave];
@@ -581,17 +613,22 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
     }
     __syncthreads();
 
+    if (MODE == MODE_LAYER) {
+        uint4 *dst = reinterpret_cast<uint4 *>(ra.layers + ((size_t)blockIdx.y * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H));
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) dst[i] = reinterpret_cast<const uint4 *>(tile)[i];
+        return;
+    }
     if (MODE == MODE_DUMP) {
         for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) {
             int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
-            if (row < fp.H && col < fp.W) key_out[(size_t)row * fp.W + col] = tile[i];
+            if (row < fp.H && col < fp.W) ra.key_out[(size_t)row * fp.W + col] = tile[i];
         }
         return;
     }
     if (MODE == MODE_COVER) {
         for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) {
             int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
-            if (row < fp.H && col < fp.W && tile[i] != KEY_EMPTY) cover[(size_t)row * fp.W + col] = 1;
+            if (row < fp.H && col < fp.W && tile[i] != KEY_EMPTY) ra.cover[(size_t)row * fp.W + col] = 1;
         }
         return;
     }
@@ -599,8 +636,8 @@ raster_score_kernel(FrameParams fp, RobotParams rp, int n_render, const float *_
     score_tile<LOSS>(tile, row0, col0, fp, n_render, tq, t32, lds_sums);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
-        const uint64_t delta = lds_sums[tid] - empty_sums[(size_t)tile_id * ROPE_SUM_WORDS + tid];
-        if (delta) atomicAdd((unsigned long long *)&sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
+        const uint64_t delta = lds_sums[tid] - ra.empty_sums[(size_t)tile_id * ROPE_SUM_WORDS + tid];
+        if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
     }
 }
 
@@ -695,45 +732,43 @@ __global__ void resolve_kernel(const uint32_t *__restrict__ key, int n, float c_
 }
 
 // ------------------------------------------------------------ launch helpers ---
-template <int MODE>
-static hipError_t launch_raster_mode(int loss, dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                                     int n_render, const float *mvp, const float *scale, const uint64_t *tq,
-                                     const float *t32, const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out,
-                                     uint8_t *cover)
+template <int LOSS, int MODE>
+static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a)
 {
-    if (MODE != MODE_SCORE) loss = ROPE_LOSS_DEPTH;
-    switch (MODE == MODE_SCORE ? loss : ROPE_LOSS_DEPTH) {
-    case ROPE_LOSS_DEPTH:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_DEPTH, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
-        break;
-    case ROPE_LOSS_FULL:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_FULL, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
-        break;
-    case ROPE_LOSS_LOOKUP:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_LOOKUP, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
-        break;
-    default:
-        hipLaunchKernelGGL((raster_score_kernel<ROPE_LOSS_TSWEEP, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
-        break;
-    }
-    return hipGetLastError();
+    hipLaunchKernelGGL((raster_score_kernel<LOSS, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, a);
 }
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
-                     const double *joint_axes, const double *PV, float *mvp, float *scale)
+                     const double *joint_axes, const double *PV, float *mvp)
 {
-    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, mvp, scale);
+    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, mvp);
     return hipGetLastError();
 }
 
-hipError_t launch_raster(int mode, int loss, int C, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                         int n_render, const float *mvp, const float *scale, const uint64_t *tq, const float *t32,
-                         const uint64_t *empty_sums, uint64_t *sums, uint32_t *key_out, uint8_t *cover)
+hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
+                         const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words)
 {
-    dim3 grid(fp.tiles_x * fp.tiles_y, C);
-    if (mode == MODE_DUMP) return launch_raster_mode<MODE_DUMP>(ROPE_LOSS_DEPTH, grid, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
-    if (mode == MODE_COVER) return launch_raster_mode<MODE_COVER>(ROPE_LOSS_DEPTH, grid, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
-    return launch_raster_mode<MODE_SCORE>(loss, grid, st, fp, rp, n_render, mvp, scale, tq, t32, empty_sums, sums, key_out, cover);
+    hipError_t e = hipMemsetAsync(mask_lo, 0, (size_t)C * mask_words * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(mask_hi, 0, (size_t)C * mask_words * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bounds_kernel, dim3((rp.n_meshlets + 255) / 256, C), dim3(256), 0, st, fp, rp, n_render, n_shared, mvp,
+                       bounds, mask_lo, mask_hi, mask_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                         const RasterArgs &a)
+{
+    dim3 grid(fp.tiles_x * fp.tiles_y, rows);
+    if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a);
+    else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a);
+    else if (mode == MODE_LAYER) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a);
+    else if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_SCORE>(grid, st, fp, rp, a);
+    else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_SCORE>(grid, st, fp, rp, a);
+    else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a);
+    else launch_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,

@@ -70,3 +70,22 @@ def test_eval_sums_and_errors_bit_exact(scene, loss, n_render):
     assert np.array_equal(sums[:, :used], sums_ref[:, :used])
     assert np.array_equal(err.view(np.uint64), err_ref.view(np.uint64))
     assert bi == int(np.argmin(err_ref)) and be == err_ref[bi]
+
+
+def test_shared_layers_do_not_change_results(scene):
+    """Links 0-2 rendered once per distinct (S, L) and composited == every candidate rendering all its links."""
+    rb, intr, PV, o, e = scene
+    d, ids = o.render([0.35, 0.45, 0.9, 0, 0, 0])
+    tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+    e.set_target(tq, t32, flags)
+    cand = helpers.slu_grid(rb.joint_limits, 5)            # 125 candidates, 25 distinct (S, L) prefixes
+    for loss, n in ((eng.LOSS_FULL, 6), (eng.LOSS_FULL, 2), (eng.LOSS_DEPTH, 4)):
+        err_a, sums_a, bi_a, _ = e.eval(cand, n, loss, want_sums=True)
+        e.debug_skip(128)
+        try:
+            err_b, sums_b, bi_b, _ = e.eval(cand, n, loss, want_sums=True)
+        finally:
+            e.debug_skip(0)
+        assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
+        err_ref = o.eval(cand[::7], loss, n, tq, t32, None, flags, threads=8)
+        assert np.array_equal(err_a[::7].view(np.uint64), err_ref.view(np.uint64))

@@ -27,7 +27,7 @@ cand = slu_grid(robot.joint_limits, grid)
 e.upload_candidates(cand)
 e.eval_resident(6, eng.LOSS_DEPTH)
 e.sync()
-names = {0: 'full', 16: 'no loss pass', 32 | 16: 'no small-tri loops, no loss', 64 | 16: 'no row pass, no loss', 32 | 64 | 16: 'setup only (no S, no rows), no loss', 8: 'no pixel loop', 8 | 16: 'no pixel loop, no loss', 4 | 16: 'no triangle phase, no loss',
+names = {0: 'full', 128: 'full, no shared layers', 16: 'no loss pass', 32 | 16: 'no small-tri loops, no loss', 64 | 16: 'no row pass, no loss', 32 | 64 | 16: 'setup only (no S, no rows), no loss', 8: 'no pixel loop', 8 | 16: 'no pixel loop, no loss', 4 | 16: 'no triangle phase, no loss',
          2 | 16: 'no vertex/triangle, no loss', 1: 'link cull + exit only'}
 for mask, name in names.items():
     e.debug_skip(mask)
