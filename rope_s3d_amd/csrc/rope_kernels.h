@@ -7,9 +7,21 @@
 
 namespace rope {
 
-constexpr int TILE_W = 128;
-constexpr int TILE_H = 64;
-constexpr int NWAVES = 8;                 // waves per workgroup of the raster kernel
+#ifndef ROPE_TILE_W
+#define ROPE_TILE_W 128
+#endif
+#ifndef ROPE_TILE_H
+#define ROPE_TILE_H 64
+#endif
+#ifndef ROPE_NWAVES
+#define ROPE_NWAVES 8
+#endif
+#ifndef ROPE_MIN_WAVES_PER_SIMD
+#define ROPE_MIN_WAVES_PER_SIMD 1
+#endif
+constexpr int TILE_W = ROPE_TILE_W;
+constexpr int TILE_H = ROPE_TILE_H;
+constexpr int NWAVES = ROPE_NWAVES;       // waves per workgroup of the raster kernel
 constexpr int NTHREADS = NWAVES * 64;
 #ifndef ROPE_SMALL_TRI_PIXELS
 #define ROPE_SMALL_TRI_PIXELS 16

@@ -178,24 +178,44 @@ __device__ static inline bool pixel_active(int row, int col, int W, int H, int r
     return row < H && col < W && row >= r0 && row <= r1 && col >= c0 && col <= c1;
 }
 
-template <int LOSS>
-__device__ static inline void score_tile(const uint32_t *tile /* LDS or nullptr = all empty */, int row0, int col0,
-                                         const FrameParams &fp, int n_render, const uint64_t *__restrict__ tq,
-                                         const float *__restrict__ t32, uint64_t *lds_sums)
+// Loss sums of one tile.  DELTA = false: plain sums (tile == nullptr means nothing rendered).
+// DELTA = true: sums(tile) - sums(same tile with nothing rendered), which only the covered samples
+// contribute to — uncovered samples are skipped without touching the target planes.  Arithmetic is
+// modulo 2^64, the frame total of the "nothing rendered" sums is added back by finalize_kernel.
+template <int LOSS, bool DELTA>
+__device__ static inline void score_tile(const uint32_t *tile, int row0, int col0, const FrameParams &fp, int n_render,
+                                         const uint64_t *__restrict__ tq, const float *__restrict__ t32, uint64_t *lds_sums)
 {
-    uint64_t s[ROPE_SUM_WORDS];
+    uint64_t s[ROPE_SUM_WORDS], e[ROPE_SUM_WORDS];
 #pragma unroll
-    for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
-    for (int i = threadIdx.x; i < TILE_W * TILE_H; i += blockDim.x) {
-        int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
-        if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-        uint32_t key = tile ? tile[i] : KEY_EMPTY;
-        score_pixel<LOSS>(key, (size_t)row * fp.W + col, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = e[k] = 0;
+    if (DELTA) {
+        for (int i4 = threadIdx.x; i4 < TILE_W * TILE_H / 4; i4 += blockDim.x) {
+            const uint4 k4 = reinterpret_cast<const uint4 *>(tile)[i4];
+            if ((k4.x & k4.y & k4.z & k4.w) == KEY_EMPTY) continue;
+            const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (keys[j] == KEY_EMPTY) continue;
+                const int i = 4 * i4 + j, row = row0 + i / TILE_W, col = col0 + i % TILE_W;
+                if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
+                const size_t pix = (size_t)row * fp.W + col;
+                score_pixel<LOSS>(keys[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+                score_pixel<LOSS>(KEY_EMPTY, pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, e);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < TILE_W * TILE_H; i += blockDim.x) {
+            int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
+            if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
+            score_pixel<LOSS>(KEY_EMPTY, (size_t)row * fp.W + col, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+        }
     }
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) {
         const bool used = (LOSS == ROPE_LOSS_FULL) ? true : (k < SUM_LINK0);
-        if (used && s[k]) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)s[k]);
+        const uint64_t d = s[k] - e[k];
+        if (used && d) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)d);
     }
 }
 
@@ -210,7 +230,7 @@ empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *
     if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
     __syncthreads();
     int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-    score_tile<LOSS>(nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, lds_sums);
+    score_tile<LOSS, false>(nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, lds_sums);
     __syncthreads();
     if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
 }
@@ -417,7 +437,7 @@ struct QEntry { uint32_t packed; float gx, gy, dc; };   // queued triangle: vert
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
 template <int LOSS, int MODE>
-__global__ void __launch_bounds__(NTHREADS)
+__global__ void __launch_bounds__(NTHREADS, ROPE_MIN_WAVES_PER_SIMD)
 raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 {
     const int n_render = ra.n_render;
@@ -633,10 +653,10 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         return;
     }
     if (fp.debug & 16) return;
-    score_tile<LOSS>(tile, row0, col0, fp, n_render, tq, t32, lds_sums);
+    score_tile<LOSS, true>(tile, row0, col0, fp, n_render, tq, t32, lds_sums);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
-        const uint64_t delta = lds_sums[tid] - ra.empty_sums[(size_t)tile_id * ROPE_SUM_WORDS + tid];
+        const uint64_t delta = lds_sums[tid];
         if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
     }
 }

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Builds tuning variants of librope_hip.so (experiments only): name -> extra hipcc defines."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
+from rope_s3d_amd import build
+VARIANTS = {
+    'base': '',
+    'w6': '-DROPE_MIN_WAVES_PER_SIMD=6',
+    't64_w6': '-DROPE_TILE_W=64 -DROPE_MIN_WAVES_PER_SIMD=6',
+    't64': '-DROPE_TILE_W=64',
+    'nw4': '-DROPE_NWAVES=4',
+    'nw16': '-DROPE_NWAVES=16',
+    's8': '-DROPE_SMALL_TRI_PIXELS=8',
+}
+for name, flags in VARIANTS.items():
+    os.environ['ROPE_HIPCC_EXTRA'] = flags
+    print(name, build.build(force=True, out_name=f'librope_hip_var_{name}.so'))
