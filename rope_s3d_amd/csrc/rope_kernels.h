@@ -23,10 +23,10 @@ constexpr int TILE_W = ROPE_TILE_W;
 constexpr int TILE_H = ROPE_TILE_H;
 constexpr int NWAVES = ROPE_NWAVES;       // waves per workgroup of the raster kernel
 constexpr int NTHREADS = NWAVES * 64;
-#ifndef ROPE_SMALL_TRI_PIXELS
-#define ROPE_SMALL_TRI_PIXELS 16
+#ifndef ROPE_SMALL_TRI_ROWS
+#define ROPE_SMALL_TRI_ROWS 4
 #endif
-constexpr int SMALL_TRI_PIXELS = ROPE_SMALL_TRI_PIXELS;   // bounding boxes up to this many samples are walked by one lane
+constexpr int SMALL_TRI_ROWS = ROPE_SMALL_TRI_ROWS;   // boxes up to 4 samples wide and this many rows are walked by one lane
 constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet list in LDS
 constexpr int MESHLET_MAX_VERTS = 128;
 constexpr int MAX_MASK_WORDS = 256;        // tile-mask words per candidate (8192 tiles)

@@ -450,6 +450,8 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __shared__ SVert s_vert[NWAVES][MESHLET_MAX_VERTS];
     __shared__ QEntry s_queue[NWAVES][64];
     __shared__ int s_qoff[NWAVES][64];
+    __shared__ unsigned long long s_qmask[NWAVES][64];
+    __shared__ int s_next;
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -478,7 +480,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         layer_tile = ra.layers + ((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
 
     if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
-    if (tid == 0) s_count = 0;
+    if (tid == 0) { s_count = 0; s_next = 0; }
     if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
     __syncthreads();
 
@@ -508,7 +510,12 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     SVert *const wv = s_vert[wave];
     QEntry *const wq = s_queue[wave];
     int *const woff = s_qoff[wave];
-    for (int li = wave; li < n_list; li += NWAVES) {
+    unsigned long long *const wmask = s_qmask[wave];
+    for (;;) {
+        int li = 0;
+        if (lane == 0) li = atomicAdd(&s_next, 1);
+        li = __builtin_amdgcn_readfirstlane(li);
+        if (li >= n_list) break;
         const int m = s_list[li];
         const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
         const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
@@ -556,14 +563,21 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                                          (edge_fn(c.X, c.Y, a.X, a.Y, fx, fy) + b20)) < 0) continue;
                                     depth_test_write(tile, px - col0, py - tf.vy0, pl, (float)(px - pxa), (float)(py - pya), l);
                                 }
-                        } else if (w * h <= SMALL_TRI_PIXELS) {
-                            if (!(fp.debug & 32))
-                            for (int py = y0; py <= y1; py++) {
-                                const int v = py - tf.vy0;
-                                for (int px = x0; px <= x1; px++) {
-                                    const int u = px - col0;
-                                    if (e0.A * u + e0.B * v >= e0.K && e1.A * u + e1.B * v >= e1.K && e2.A * u + e2.B * v >= e2.K)
-                                        depth_test_write(tile, u, v, pl, (float)(px - pxa), (float)(py - pya), l);
+                        } else if (w <= 4 && h <= SMALL_TRI_ROWS) {
+                            // small box: walk its rows, four samples of a row at a time without branching on coverage tests
+                            if (!(fp.debug & 32)) {
+                                const int u0 = x0 - col0;
+                                int t0 = e0.A * u0 + e0.B * (y0 - tf.vy0), t1 = e1.A * u0 + e1.B * (y0 - tf.vy0),
+                                    t2 = e2.A * u0 + e2.B * (y0 - tf.vy0);
+                                const float dx0 = (float)(x0 - pxa);
+                                for (int py = y0; py <= y1; py++, t0 += e0.B, t1 += e1.B, t2 += e2.B) {
+                                    const int v = py - tf.vy0;
+                                    const float dyf = (float)(py - pya);
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        const bool in = (j < w) && (t0 + j * e0.A >= e0.K) && (t1 + j * e1.A >= e1.K) && (t2 + j * e2.A >= e2.K);
+                                        if (in) depth_test_write(tile, u0 + j, v, pl, dx0 + (float)j, dyf, l);
+                                    }
                                 }
                             }
                         } else {
@@ -573,43 +587,40 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                     }
                 }
             }
-            // ---- queue the larger triangles, then spread their rows over the lanes
+            // ---- queue the larger triangles, then spread their rows over the lanes.  Queue order is lane
+            // order, so a scan of `rows` over the lanes gives every queued triangle its first item; the
+            // owner of an item is found from a per-chunk bit mask of "a triangle starts at this item".
             const unsigned long long qmask = __ballot(rows > 0);
             if (qmask == 0 || (fp.debug & 64)) continue;
-            const int qn = __popcll(qmask);
-            const int qpos = __popcll(qmask & ((1ull << lane) - 1));
-            if (rows > 0) wq[qpos] = qe;
-            // exclusive prefix of rows in queue order: lane i scans entry i
-            int incl;
-            {
-                // hand entry order to lanes 0..qn-1: lane with rows>0 publishes rows at its queue slot
-                if (rows > 0) woff[qpos] = rows;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                incl = lane < qn ? woff[lane] : 0;
+            int incl = rows;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += o;
-                }
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
             }
             const int total = __shfl(incl, 63, 64);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < qn) woff[lane] = incl;      // inclusive ends: entry e owns items [woff[e-1], woff[e])
+            const int excl = incl - rows;
+            const int qpos = __popcll(qmask & ((1ull << lane) - 1));
+            const int nchunks = (total + 63) >> 6;
+            if (lane < nchunks) wmask[lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int base = 0; base < total; base += 64) {
-                const int item = base + lane;
+            if (rows > 0) {
+                wq[qpos] = qe;
+                woff[qpos] = excl;
+                atomicOr(&wmask[excl >> 6], 1ull << (excl & 63));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int chunk = 0; chunk < nchunks; chunk++) {
+                const int base = chunk << 6, item = base + lane;
+                const int before = __popcll(__ballot(rows > 0 && excl < base));   // triangles that start in earlier chunks
                 if (item < total) {
-                    // first entry whose inclusive end exceeds item
-                    int lo = 0, hi = qn - 1;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (woff[mid] > item) hi = mid; else lo = mid + 1;
-                    }
-                    const int r = item - (lo > 0 ? woff[lo - 1] : 0);
+                    const unsigned long long mk = wmask[chunk];
+                    const int lo = before + __popcll(mk & ((2ull << lane) - 1ull)) - 1;
+                    const int r = item - woff[lo];
                     const QEntry e = wq[lo];
                     const SVert a = wv[e.packed & 0xFF], b = wv[(e.packed >> 8) & 0xFF], c = wv[(e.packed >> 16) & 0xFF];
                     const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
