@@ -157,7 +157,7 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
             uint32_t v0 = h[4], t0 = h[5], nv = h[6] & 0xFFFF, nt = h[6] >> 16;
             if (h[7] != (uint32_t)l) ARG_FAIL(c, "rope_set_robot: meshlet link id mismatch");
             if (nv < 1 || nv > MESHLET_MAX_VERTS || (size_t)v0 + nv > (size_t)n_ml_verts) ARG_FAIL(c, "rope_set_robot: meshlet vertex range");
-            if (nt < 1 || (size_t)t0 + nt > (size_t)n_ml_tris) ARG_FAIL(c, "rope_set_robot: meshlet triangle range");
+            if (nt < 1 || nt > MESHLET_MAX_TRIS || (size_t)t0 + nt > (size_t)n_ml_tris) ARG_FAIL(c, "rope_set_robot: meshlet triangle range");
             for (uint32_t t = 0; t < nt; t++) {
                 uint32_t p = ml_tris[t0 + t];
                 if ((p & 0xFF) >= nv || ((p >> 8) & 0xFF) >= nv || ((p >> 16) & 0xFF) >= nv) ARG_FAIL(c, "rope_set_robot: triangle index outside its meshlet");

@@ -26,9 +26,14 @@ constexpr int NTHREADS = NWAVES * 64;
 #ifndef ROPE_SMALL_TRI_ROWS
 #define ROPE_SMALL_TRI_ROWS 4
 #endif
+#ifndef ROPE_SMALL_TRI_COLS
+#define ROPE_SMALL_TRI_COLS 4
+#endif
+constexpr int SMALL_TRI_COLS = ROPE_SMALL_TRI_COLS;
 constexpr int SMALL_TRI_ROWS = ROPE_SMALL_TRI_ROWS;   // boxes up to 4 samples wide and this many rows are walked by one lane
 constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet list in LDS
 constexpr int MESHLET_MAX_VERTS = 128;
+constexpr int MESHLET_MAX_TRIS = 128;
 constexpr int MAX_MASK_WORDS = 256;        // tile-mask words per candidate (8192 tiles)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t D24_MAX = 16777215u;

@@ -452,6 +452,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __shared__ int s_qoff[NWAVES][64];
     __shared__ unsigned long long s_qmask[NWAVES][64];
     __shared__ int s_next;
+    __shared__ uint32_t s_keep[NWAVES][MESHLET_MAX_TRIS];
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -511,6 +512,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     QEntry *const wq = s_queue[wave];
     int *const woff = s_qoff[wave];
     unsigned long long *const wmask = s_qmask[wave];
+    uint32_t *const wkeep = s_keep[wave];
     for (;;) {
         int li = 0;
         if (lane == 0) li = atomicAdd(&s_next, 1);
@@ -530,13 +532,15 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (fp.debug & 4) continue;
+        // ---- pass 1: cull.  Keep front-facing triangles whose bounding box holds a sample of this tile and
+        // compact them, so that the expensive set-up below runs on full lanes (about one triangle in four survives).
+        int ns = 0;
         for (int tb = 0; tb < nt; tb += 64) {
-            // ---- per-lane set-up: cull, classify, rasterise the small ones in place
-            int rows = 0;                          // > 0: queued for the row-parallel pass
-            QEntry qe;
             const int t = tb + lane;
+            bool keep = false;
+            uint32_t packed = 0;
             if (t < nt) {
-                const uint32_t packed = rp.ml_tris[t0 + t];
+                packed = rp.ml_tris[t0 + t];
                 const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
                 if (a.X != SV_BAD && b.X != SV_BAD && c.X != SV_BAD) {
                     const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
@@ -544,8 +548,32 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                     const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
                     const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
                     const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
-                    // front-facing (CCW) with at least one sample centre inside its bounding box
-                    if (area2 > 0 && x0 <= x1 && y0 <= y1 && !(fp.debug & 8)) {
+                    keep = area2 > 0 && x0 <= x1 && y0 <= y1;
+                }
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) wkeep[ns + __popcll(km & ((1ull << lane) - 1))] = packed;
+            ns += __popcll(km);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fp.debug & 8) continue;
+        // ---- pass 2: set-up, classify, rasterise
+        for (int tb = 0; tb < ns; tb += 64) {
+            int rows = 0;                          // > 0: queued for the row-parallel pass
+            QEntry qe;
+            const int t = tb + lane;
+            if (t < ns) {
+                const uint32_t packed = wkeep[t];
+                const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
+                {
+                    const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
+                    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
+                    const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
+                    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
+                    const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
+                    {
                         const Plane pl = make_plane(a, b, c, area2);
                         const int32_t pxa = a.X >> 8, pya = a.Y >> 8;
                         const Edge e0 = make_edge(a.X, a.Y, b.X, b.Y, tf), e1 = make_edge(b.X, b.Y, c.X, c.Y, tf),
@@ -563,7 +591,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                                          (edge_fn(c.X, c.Y, a.X, a.Y, fx, fy) + b20)) < 0) continue;
                                     depth_test_write(tile, px - col0, py - tf.vy0, pl, (float)(px - pxa), (float)(py - pya), l);
                                 }
-                        } else if (w <= 4 && h <= SMALL_TRI_ROWS) {
+                        } else if (w <= SMALL_TRI_COLS && h <= SMALL_TRI_ROWS) {
                             // small box: walk its rows, four samples of a row at a time without branching on coverage tests
                             if (!(fp.debug & 32)) {
                                 const int u0 = x0 - col0;
@@ -574,7 +602,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                                     const int v = py - tf.vy0;
                                     const float dyf = (float)(py - pya);
 #pragma unroll
-                                    for (int j = 0; j < 4; j++) {
+                                    for (int j = 0; j < SMALL_TRI_COLS; j++) {
                                         const bool in = (j < w) && (t0 + j * e0.A >= e0.K) && (t1 + j * e1.A >= e1.K) && (t2 + j * e2.A >= e2.K);
                                         if (in) depth_test_write(tile, u0 + j, v, pl, dx0 + (float)j, dyf, l);
                                     }

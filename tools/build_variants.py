@@ -4,13 +4,12 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd import build
 VARIANTS = {
-    'base': '',
-    'w6': '-DROPE_MIN_WAVES_PER_SIMD=6',
-    't64_w6': '-DROPE_TILE_W=64 -DROPE_MIN_WAVES_PER_SIMD=6',
-    't64': '-DROPE_TILE_W=64',
-    'nw4': '-DROPE_NWAVES=4',
-    'nw16': '-DROPE_NWAVES=16',
-    's8': '-DROPE_SMALL_TRI_PIXELS=8',
+    'c4r4': '',
+    'c8r4': '-DROPE_SMALL_TRI_COLS=8',
+    'c8r8': '-DROPE_SMALL_TRI_COLS=8 -DROPE_SMALL_TRI_ROWS=8',
+    'c4r8': '-DROPE_SMALL_TRI_ROWS=8',
+    'c6r6': '-DROPE_SMALL_TRI_COLS=6 -DROPE_SMALL_TRI_ROWS=6',
+    'c2r2': '-DROPE_SMALL_TRI_COLS=2 -DROPE_SMALL_TRI_ROWS=2',
 }
 for name, flags in VARIANTS.items():
     os.environ['ROPE_HIPCC_EXTRA'] = flags
