@@ -401,11 +401,9 @@ __device__ static inline int ceil_div_pos(int32_t n, int32_t A, float rcpA)
 {
     float q = ceilf((float)n * rcpA);
     q = fminf(fmaxf(q, -3.0f), (float)(TILE_W + 2));
-    int u = (int)q;
-    u += (A * u < n);
-    u += (A * u < n);
-    u -= (A * (u - 1) >= n);
-    u -= (A * (u - 1) >= n);
+    int u = (int)q;                                  // within 1 of the answer when that lies in range
+    u += (__mul24(A, u) < n);
+    u -= (__mul24(A, u - 1) >= n);
     return u;
 }
 
@@ -415,17 +413,15 @@ __device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
     float q = floorf((float)n * rcpA);
     q = fminf(fmaxf(q, -3.0f), (float)(TILE_W + 2));
     int u = (int)q;
-    u -= (A * u > n);
-    u -= (A * u > n);
-    u += (A * (u + 1) <= n);
-    u += (A * (u + 1) <= n);
+    u -= (__mul24(A, u) > n);
+    u += (__mul24(A, u + 1) <= n);
     return u;
 }
 
 // Samples of row v covered by the half-space: narrows [lo,hi].
 __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
 {
-    const int32_t n = e.K - e.B * v;               // A*u >= n
+    const int32_t n = e.K - __mul24(e.B, v);       // A*u >= n   (|B| < 2^22, 0 <= v < TILE_H)
     if (e.A > 0) lo = max(lo, ceil_div_pos(n, e.A, __builtin_amdgcn_rcpf((float)e.A)));
     else if (e.A < 0) hi = min(hi, floor_div_pos(-n, -e.A, __builtin_amdgcn_rcpf((float)(-e.A))));
     else if (n > 0) hi = -1;
@@ -595,8 +591,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                             // small box: walk its rows, four samples of a row at a time without branching on coverage tests
                             if (!(fp.debug & 32)) {
                                 const int u0 = x0 - col0;
-                                int t0 = e0.A * u0 + e0.B * (y0 - tf.vy0), t1 = e1.A * u0 + e1.B * (y0 - tf.vy0),
-                                    t2 = e2.A * u0 + e2.B * (y0 - tf.vy0);
+                                const int vv = y0 - tf.vy0;       // coefficients are below 2^22 here, u0 and vv below 2^8
+                                int t0 = __mul24(e0.A, u0) + __mul24(e0.B, vv), t1 = __mul24(e1.A, u0) + __mul24(e1.B, vv),
+                                    t2 = __mul24(e2.A, u0) + __mul24(e2.B, vv);
                                 const float dx0 = (float)(x0 - pxa);
                                 for (int py = y0; py <= y1; py++, t0 += e0.B, t1 += e1.B, t2 += e2.B) {
                                     const int v = py - tf.vy0;

@@ -4,12 +4,12 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd import build
 VARIANTS = {
-    'c4r4': '',
-    'c8r4': '-DROPE_SMALL_TRI_COLS=8',
-    'c8r8': '-DROPE_SMALL_TRI_COLS=8 -DROPE_SMALL_TRI_ROWS=8',
-    'c4r8': '-DROPE_SMALL_TRI_ROWS=8',
-    'c6r6': '-DROPE_SMALL_TRI_COLS=6 -DROPE_SMALL_TRI_ROWS=6',
-    'c2r2': '-DROPE_SMALL_TRI_COLS=2 -DROPE_SMALL_TRI_ROWS=2',
+    'base': '',
+    'h128_nw16': '-DROPE_TILE_H=128 -DROPE_NWAVES=16',
+    'w256_nw16': '-DROPE_TILE_W=256 -DROPE_NWAVES=16',
+    'nw16': '-DROPE_NWAVES=16',
+    'nw4': '-DROPE_NWAVES=4',
+    'w64': '-DROPE_TILE_W=64',
 }
 for name, flags in VARIANTS.items():
     os.environ['ROPE_HIPCC_EXTRA'] = flags
