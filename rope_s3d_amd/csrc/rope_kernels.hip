@@ -427,7 +427,6 @@ __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
     else if (n > 0) hi = -1;
 }
 
-struct QEntry { uint32_t packed; float gx, gy, dc; };   // queued triangle: vertex indices + depth plane
 
 // MODE_SCORE: reduce the loss and add (actual - empty) into the candidate's sums.
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
@@ -444,7 +443,6 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __shared__ uint16_t s_list[MAX_MESHLETS];
     __shared__ int s_count;
     __shared__ SVert s_vert[NWAVES][MESHLET_MAX_VERTS];
-    __shared__ QEntry s_queue[NWAVES][64];
     __shared__ int s_qoff[NWAVES][64];
     __shared__ unsigned long long s_qmask[NWAVES][64];
     __shared__ int s_next;
@@ -505,7 +503,6 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 
     // --- one meshlet per wave at a time
     SVert *const wv = s_vert[wave];
-    QEntry *const wq = s_queue[wave];
     int *const woff = s_qoff[wave];
     unsigned long long *const wmask = s_qmask[wave];
     uint32_t *const wkeep = s_keep[wave];
@@ -558,7 +555,10 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         // ---- pass 2: set-up, classify, rasterise
         for (int tb = 0; tb < ns; tb += 64) {
             int rows = 0;                          // > 0: queued for the row-parallel pass
-            QEntry qe;
+            // what a queued triangle's owner lane keeps for the lanes that will take its rows
+            Edge q0 = {0, 0, 0}, q1 = {0, 0, 0}, q2 = {0, 0, 0};
+            Plane qpl = {0.0f, 0.0f, 0.0f};
+            int q_ulo = 0, q_uhi = -1, q_v0 = 0, q_dxa = 0, q_dya = 0;
             const int t = tb + lane;
             if (t < ns) {
                 const uint32_t packed = wkeep[t];
@@ -607,7 +607,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                             }
                         } else {
                             rows = h;
-                            qe.packed = packed; qe.gx = pl.gx; qe.gy = pl.gy; qe.dc = pl.dc;
+                            q0 = e0; q1 = e1; q2 = e2; qpl = pl;
+                            q_ulo = x0 - col0; q_uhi = x1 - col0; q_v0 = y0 - tf.vy0;
+                            q_dxa = col0 - pxa; q_dya = tf.vy0 - pya;
                         }
                     }
                 }
@@ -632,34 +634,35 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (rows > 0) {
-                wq[qpos] = qe;
-                woff[qpos] = excl;
+                woff[qpos] = excl | (lane << 16);          // first item (total <= 4096) and owner lane of slot qpos
                 atomicOr(&wmask[excl >> 6], 1ull << (excl & 63));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int qn = __popcll(qmask);
             for (int chunk = 0; chunk < nchunks; chunk++) {
                 const int base = chunk << 6, item = base + lane;
                 const int before = __popcll(__ballot(rows > 0 && excl < base));   // triangles that start in earlier chunks
+                const unsigned long long mk = wmask[chunk];
+                const int slot = max(min(before + __popcll(mk & ((2ull << lane) - 1ull)) - 1, qn - 1), 0);
+                const int so = woff[slot];
+                const int src = so >> 16;                      // owner lane: its registers hold the set-up
+                // every lane takes part in the exchanges (inactive source lanes would read as garbage)
+                Edge e0, e1, e2;
+                e0.A = __shfl(q0.A, src, 64); e0.B = __shfl(q0.B, src, 64); e0.K = __shfl(q0.K, src, 64);
+                e1.A = __shfl(q1.A, src, 64); e1.B = __shfl(q1.B, src, 64); e1.K = __shfl(q1.K, src, 64);
+                e2.A = __shfl(q2.A, src, 64); e2.B = __shfl(q2.B, src, 64); e2.K = __shfl(q2.K, src, 64);
+                Plane pl;
+                pl.gx = __shfl(qpl.gx, src, 64); pl.gy = __shfl(qpl.gy, src, 64); pl.dc = __shfl(qpl.dc, src, 64);
+                int ulo = __shfl(q_ulo, src, 64), uhi = __shfl(q_uhi, src, 64);
+                const int v0q = __shfl(q_v0, src, 64), dxa = __shfl(q_dxa, src, 64), dya = __shfl(q_dya, src, 64);
                 if (item < total) {
-                    const unsigned long long mk = wmask[chunk];
-                    const int lo = before + __popcll(mk & ((2ull << lane) - 1ull)) - 1;
-                    const int r = item - woff[lo];
-                    const QEntry e = wq[lo];
-                    const SVert a = wv[e.packed & 0xFF], b = wv[(e.packed >> 8) & 0xFF], c = wv[(e.packed >> 16) & 0xFF];
-                    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
-                    const int32_t minY = min(a.Y, min(b.Y, c.Y));
-                    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
-                    const int y0 = max(-((-(minY - 128)) >> 8), wy0);
-                    const int py = y0 + r, v = py - tf.vy0;
-                    int ulo = x0 - col0, uhi = x1 - col0;
-                    clip_span(make_edge(a.X, a.Y, b.X, b.Y, tf), v, ulo, uhi);
-                    clip_span(make_edge(b.X, b.Y, c.X, c.Y, tf), v, ulo, uhi);
-                    clip_span(make_edge(c.X, c.Y, a.X, a.Y, tf), v, ulo, uhi);
-                    const Plane pl = {e.gx, e.gy, e.dc};
-                    const float dy = (float)(py - (a.Y >> 8));
-                    const int dxa = col0 - (a.X >> 8);
+                    const int v = v0q + (item - (so & 0xFFFF));
+                    clip_span(e0, v, ulo, uhi);
+                    clip_span(e1, v, ulo, uhi);
+                    clip_span(e2, v, ulo, uhi);
+                    const float dy = (float)(v + dya);
                     for (int u = ulo; u <= uhi; u++) depth_test_write(tile, u, v, pl, (float)(u + dxa), dy, l);
                 }
             }
