@@ -11,7 +11,7 @@ namespace rope {
 #define ROPE_TILE_W 128
 #endif
 #ifndef ROPE_TILE_H
-#define ROPE_TILE_H 64
+#define ROPE_TILE_H 48
 #endif
 #ifndef ROPE_NWAVES
 #define ROPE_NWAVES 8

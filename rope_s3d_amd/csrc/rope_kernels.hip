@@ -515,11 +515,18 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
         const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
         const uint32_t l = h1.w;
-        const float *mm = s_mvp + 16 * l;
         if (fp.debug & 2) continue;
-        for (int v = lane; v < nv; v += 64) {
-            const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
-            wv[v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
+        {
+            // the link matrix is the same for the whole wave: keep it in scalar registers
+            float mm[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                mm[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_mvp[16 * l + k])));
+#pragma unroll 1
+            for (int v = lane; v < nv; v += 64) {
+                const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
+                wv[v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

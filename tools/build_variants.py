@@ -5,11 +5,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.p
 from rope_s3d_amd import build
 VARIANTS = {
     'base': '',
-    'h128_nw16': '-DROPE_TILE_H=128 -DROPE_NWAVES=16',
-    'w256_nw16': '-DROPE_TILE_W=256 -DROPE_NWAVES=16',
-    'nw16': '-DROPE_NWAVES=16',
-    'nw4': '-DROPE_NWAVES=4',
-    'w64': '-DROPE_TILE_W=64',
+    'h48_w6': '-DROPE_TILE_H=48 -DROPE_MIN_WAVES_PER_SIMD=6',
+    'h32_w6': '-DROPE_TILE_H=32 -DROPE_MIN_WAVES_PER_SIMD=6',
+    'h48': '-DROPE_TILE_H=48',
 }
 for name, flags in VARIANTS.items():
     os.environ['ROPE_HIPCC_EXTRA'] = flags
