@@ -56,6 +56,7 @@ struct rope_ctx {
     int n_layers = 0;
     int32_t *d_layer_of = nullptr, *d_layer_rep = nullptr;
     uint32_t *d_layers = nullptr;
+    uint64_t *d_layer_sums = nullptr;
     size_t layers_cap = 0;                 // keys allocated in d_layers
     int layer_rep_cap = 0;
     uint64_t *d_sums = nullptr;
@@ -128,7 +129,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -355,6 +356,7 @@ static int ensure_layers(rope_ctx *c)
     if (need <= c->layers_cap) return ROPE_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, realloc_dev(&c->d_layers, need));
+    HIP_TRY(c, realloc_dev(&c->d_layer_sums, (size_t)c->n_layers * c->n_tiles * ROPE_SUM_WORDS));
     c->layers_cap = need;
     return ROPE_OK;
 }
@@ -383,8 +385,9 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     if (layers) {
         RasterArgs la = a;
         la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
+        la.layer_sums = c->d_layer_sums; la.tq = c->d_tq; la.t32 = c->d_t32;
         HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
-        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers;
+        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
     a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss]; a.sums = c->d_sums;
     HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));

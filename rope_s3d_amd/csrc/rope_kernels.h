@@ -17,7 +17,7 @@ namespace rope {
 #define ROPE_NWAVES 8
 #endif
 #ifndef ROPE_MIN_WAVES_PER_SIMD
-#define ROPE_MIN_WAVES_PER_SIMD 1
+#define ROPE_MIN_WAVES_PER_SIMD 6
 #endif
 constexpr int TILE_W = ROPE_TILE_W;
 constexpr int TILE_H = ROPE_TILE_H;
@@ -74,6 +74,7 @@ struct RasterArgs {
     const int32_t *cand_of_row;           // MODE_LAYER: layer -> representative candidate; else nullptr
     const int32_t *layer_of;              // candidate -> layer, nullptr when layers are not in use
     uint32_t *layers;                     // n_layers x n_tiles x (TILE_W*TILE_H) keys
+    uint64_t *layer_sums;                 // n_layers x n_tiles x ROPE_SUM_WORDS: loss sums of the layer alone
     const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
     uint64_t *sums; uint32_t *key_out; uint8_t *cover;
 };

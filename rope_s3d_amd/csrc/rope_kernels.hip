@@ -120,7 +120,16 @@ __device__ static inline float linear_depth(uint32_t d24, float c_num, float c_s
     return c_num / den;
 }
 
-__device__ static inline uint64_t q32_of_f32(float z) { return (uint64_t)((double)z * 4294967296.0); }
+// floor(z * 2^32) for a finite z >= 0, by shifting the significand (same value as (uint64_t)((double)z * 2^32)).
+__device__ static inline uint64_t q32_of_f32(float z)
+{
+    const uint32_t b = __float_as_uint(z);
+    const int ex = (int)(b >> 23) & 0xFF;
+    if (ex == 0) return 0;                                   // zero and denormals: below one unit of 2^-32
+    const uint64_t m = (uint64_t)((b & 0x7FFFFFu) | 0x800000u);
+    const int sh = ex - 127 - 23 + 32;                        // z = m * 2^(ex-150)
+    return sh >= 0 ? (m << sh) : (sh > -64 ? (m >> -sh) : 0);
+}
 
 struct Acc {
     uint64_t w[ROPE_SUM_WORDS];
@@ -178,30 +187,33 @@ __device__ static inline bool pixel_active(int row, int col, int W, int H, int r
     return row < H && col < W && row >= r0 && row <= r1 && col >= c0 && col <= c1;
 }
 
-// Loss sums of one tile.  DELTA = false: plain sums (tile == nullptr means nothing rendered).
-// DELTA = true: sums(tile) - sums(same tile with nothing rendered), which only the covered samples
-// contribute to — uncovered samples are skipped without touching the target planes.  Arithmetic is
+// Loss sums of one tile.  DELTA = false: plain sums of a tile with nothing rendered.
+// DELTA = true: sums(tile) - sums(base tile), which only the samples whose key differs contribute to —
+// all others are skipped without touching the target planes.  Arithmetic is
 // modulo 2^64, the frame total of the "nothing rendered" sums is added back by finalize_kernel.
 template <int LOSS, bool DELTA>
-__device__ static inline void score_tile(const uint32_t *tile, int row0, int col0, const FrameParams &fp, int n_render,
+__device__ static inline void score_tile(const uint32_t *tile, const uint32_t *__restrict__ base /* global, or nullptr = nothing */,
+                                         int row0, int col0, const FrameParams &fp, int n_render,
                                          const uint64_t *__restrict__ tq, const float *__restrict__ t32, uint64_t *lds_sums)
 {
     uint64_t s[ROPE_SUM_WORDS], e[ROPE_SUM_WORDS];
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = e[k] = 0;
     if (DELTA) {
+        // only samples whose key differs from the base tile (the shared layer, or nothing) change the sums
         for (int i4 = threadIdx.x; i4 < TILE_W * TILE_H / 4; i4 += blockDim.x) {
             const uint4 k4 = reinterpret_cast<const uint4 *>(tile)[i4];
-            if ((k4.x & k4.y & k4.z & k4.w) == KEY_EMPTY) continue;
-            const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w};
+            const uint4 b4 = base ? reinterpret_cast<const uint4 *>(base)[i4] : make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
+            if (k4.x == b4.x && k4.y == b4.y && k4.z == b4.z && k4.w == b4.w) continue;
+            const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w}, bas[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (keys[j] == KEY_EMPTY) continue;
+                if (keys[j] == bas[j]) continue;
                 const int i = 4 * i4 + j, row = row0 + i / TILE_W, col = col0 + i % TILE_W;
                 if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
                 const size_t pix = (size_t)row * fp.W + col;
                 score_pixel<LOSS>(keys[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
-                score_pixel<LOSS>(KEY_EMPTY, pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, e);
+                score_pixel<LOSS>(bas[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, e);
             }
         }
     } else {
@@ -230,7 +242,7 @@ empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *
     if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
     __syncthreads();
     int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-    score_tile<LOSS, false>(nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, lds_sums);
+    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, lds_sums);
     __syncthreads();
     if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
 }
@@ -491,6 +503,16 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             }
         }
     }
+    __syncthreads();
+    const int n_list = s_count;
+    if (n_list == 0 && MODE != MODE_LAYER) {
+        // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
+        if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
+            const uint64_t d = ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
+            if (d) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)d);
+        }
+        return;
+    }
     if (layer_tile) {
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
             reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(layer_tile)[i];
@@ -498,8 +520,6 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
     }
     __syncthreads();
-    const int n_list = s_count;
-    if (n_list == 0 && !layer_tile && MODE != MODE_LAYER) return;   // nothing lands in this tile: its sums stay "empty"
 
     // --- one meshlet per wave at a time
     SVert *const wv = s_vert[wave];
@@ -680,8 +700,13 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __syncthreads();
 
     if (MODE == MODE_LAYER) {
-        uint4 *dst = reinterpret_cast<uint4 *>(ra.layers + ((size_t)blockIdx.y * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H));
+        const size_t slot = (size_t)blockIdx.y * (fp.tiles_x * fp.tiles_y) + tile_id;
+        uint4 *dst = reinterpret_cast<uint4 *>(ra.layers + slot * (TILE_W * TILE_H));
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) dst[i] = reinterpret_cast<const uint4 *>(tile)[i];
+        // loss sums of the layer alone (relative to "nothing rendered"): every candidate on this layer starts from them
+        score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, lds_sums);
+        __syncthreads();
+        if (tid < ROPE_SUM_WORDS) ra.layer_sums[slot * ROPE_SUM_WORDS + tid] = lds_sums[tid];
         return;
     }
     if (MODE == MODE_DUMP) {
@@ -699,10 +724,11 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         return;
     }
     if (fp.debug & 16) return;
-    score_tile<LOSS, true>(tile, row0, col0, fp, n_render, tq, t32, lds_sums);
+    score_tile<LOSS, true>(tile, layer_tile, row0, col0, fp, n_render, tq, t32, lds_sums);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
-        const uint64_t delta = lds_sums[tid];
+        uint64_t delta = lds_sums[tid];
+        if (layer_tile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
         if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
     }
 }
@@ -829,7 +855,12 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
     dim3 grid(fp.tiles_x * fp.tiles_y, rows);
     if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a);
     else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a);
-    else if (mode == MODE_LAYER) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a);
+    else if (mode == MODE_LAYER) {
+        if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a);
+        else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a);
+        else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_LAYER>(grid, st, fp, rp, a);
+        else launch_one<ROPE_LOSS_TSWEEP, MODE_LAYER>(grid, st, fp, rp, a);
+    }
     else if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_SCORE>(grid, st, fp, rp, a);
     else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_SCORE>(grid, st, fp, rp, a);
     else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a);
