@@ -1,0 +1,164 @@
+"""GPU: properties at BASELINE.json's full sizes (640x480, 4096 candidates; 1280x720 mh50), where the CPU oracle
+would take minutes, plus edge cases of the C ABI."""
+import numpy as np
+import pytest
+
+from rope_s3d_amd import engine as eng
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
+from rope_s3d_amd.projection import Intrinsics, view_matrix
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(rb, preset, pose=DEFAULT_CAMERA_POSE, ds=1):
+    intr, PV = helpers.camera(preset, ds=ds, pose=pose)
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+    return e, intr, PV
+
+
+@pytest.fixture(scope='module')
+def full():
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '640_480_color')
+    q_true = np.random.default_rng(7919).uniform(rb.joint_limits[:, 0], rb.joint_limits[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    depth, ids = e.render(q_true, 6)
+    tq, t32, flags, *_ = helpers.synthetic_target(depth, ids)
+    e.set_target(tq, t32, flags)
+    return rb, e, q_true, depth, ids, (tq, t32, flags)
+
+
+def test_render_against_itself_has_zero_difference(full):
+    """Scoring the target's own pose: every sample matches bit for bit, so no D != 0 and no mask mismatch."""
+    rb, e, q_true, depth, ids, _ = full
+    err, sums, _, _ = e.eval(q_true[None], 6, eng.LOSS_FULL, want_sums=True)
+    assert sums[0, 0] == 0 and sums[0, 1] == 0            # count and sum of non-zero depth differences
+    assert all(sums[0, 5 + 3 * l] == 0 for l in range(1, 6))   # per-link mask mismatches
+    assert np.isnan(err[0])                                # mean of an empty selection, as numpy (predict.py:507)
+
+
+def test_full_grid_is_permutation_equivariant_and_repeatable(full):
+    rb, e, *_ = full
+    cand = helpers.slu_grid(rb.joint_limits, 16)           # 4096 candidates (BASELINE configs[1])
+    err_a, sums_a, bi_a, be_a = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+    err_b, sums_b, bi_b, _ = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+    assert np.array_equal(sums_a, sums_b) and bi_a == bi_b             # atomics in any order, same bits
+    perm = np.random.default_rng(3).permutation(len(cand))
+    err_p, sums_p, bi_p, be_p = e.eval(cand[perm], 6, eng.LOSS_DEPTH, want_sums=True)
+    assert np.array_equal(sums_p, sums_a[perm])                        # grouping into shared layers changes nothing
+    assert np.array_equal(err_p.view(np.uint64), err_a[perm].view(np.uint64))
+    assert be_p == be_a and perm[bi_p] == bi_a or err_a[perm[bi_p]] == be_a
+    assert bi_a == int(np.nanargmin(err_a))
+
+
+def test_full_grid_layers_equal_direct_rendering(full):
+    rb, e, *_ = full
+    cand = helpers.slu_grid(rb.joint_limits, 16)
+    for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL):
+        _, sums_a, bi_a, _ = e.eval(cand, 6, loss, want_sums=True)
+        e.debug_skip(128)
+        try:
+            _, sums_b, bi_b, _ = e.eval(cand, 6, loss, want_sums=True)
+        finally:
+            e.debug_skip(0)
+        assert np.array_equal(sums_a, sums_b) and bi_a == bi_b
+
+
+def test_mismatch_counts_match_rendered_images(full):
+    """Integer link-mismatch sums of the engine == the same counts taken from its own rendered id images."""
+    rb, e, q_true, depth, ids, _ = full
+    for q in ([0.2, 0.1, 0.5, 0, 0, 0], [1.2, -0.5, 2.0, 0, 0, 0]):
+        _, sums, _, _ = e.eval(np.array([q]), 6, eng.LOSS_FULL, want_sums=True)
+        d_r, id_r = e.render(q, 6)
+        for l in range(1, 6):
+            assert sums[0, 5 + 3 * l] == np.count_nonzero((ids == l) != (id_r == l))
+        D = np.abs(depth.astype(np.float64) - d_r)
+        assert sums[0, 0] == np.count_nonzero(D)
+        assert abs(sums[0, 1] / 2.0 ** 32 - D.sum()) <= 1e-9 * D.sum() + 1e-6
+
+
+def test_mh50_1280x720_against_oracle():
+    """BASELINE configs[4] geometry: other robot, other resolution (150 tiles, partial tile columns/rows)."""
+    rb = helpers.robot('urdfs/motoman_mh50_support/urdf/mh50.urdf')
+    pose = [0, -4.0, 1.5, 0, 0, 0]
+    e, intr, PV = make_engine(rb, '1280_720_color', pose)
+    o = helpers.make_oracle(rb, intr, PV)
+    q = [0.4, 0.3, 0.2, 0.5, -0.4, 1.0]
+    d_ref, id_ref = o.render(q, 6)
+    d, ids = e.render(q, 6)
+    assert (id_ref != 255).sum() > 20000
+    assert np.array_equal(ids, id_ref) and np.array_equal(d.view(np.uint32), d_ref.view(np.uint32))
+    tq, t32, flags, *_ = helpers.synthetic_target(d_ref, id_ref)
+    e.set_target(tq, t32, flags)
+    cand = helpers.slu_grid(rb.joint_limits, 3)
+    err_ref, sums_ref = o.eval(cand, 1, 6, tq, t32, None, flags, threads=8, want_sums=True)
+    err, sums, bi, _ = e.eval(cand, 6, eng.LOSS_FULL, want_sums=True)
+    assert np.array_equal(sums, sums_ref) and np.array_equal(err.view(np.uint64), err_ref.view(np.uint64))
+
+
+@pytest.mark.parametrize('ds', [8, 5])
+def test_ragged_resolutions_against_oracle(ds):
+    """160x90 and 256x144: neither dimension is a multiple of the 128x48 tile."""
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '1280_720_color', ds=ds)
+    o = helpers.make_oracle(rb, intr, PV)
+    for q in ([0.3, 0.4, 0.5, 0, 0, 0], [-0.7, 1.5, -0.8, 1, 1, 1]):
+        d_ref, id_ref = o.render(q, 6)
+        d, ids = e.render(q, 6)
+        assert np.array_equal(ids, id_ref) and np.array_equal(d.view(np.uint32), d_ref.view(np.uint32))
+
+
+def test_robot_partly_and_wholly_out_of_view():
+    """Close camera: triangles cross the image border and the near plane; far-away look direction: nothing drawn."""
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '640_480_color', pose=[0.1, -0.45, 0.5, 0, 0.3, 0.2], ds=2)
+    o = helpers.make_oracle(rb, intr, PV)
+    d_ref, id_ref = o.render([0.5, 0.5, 0.5, 0, 0, 0], 6)
+    d, ids = e.render([0.5, 0.5, 0.5, 0, 0, 0], 6)
+    assert np.array_equal(ids, id_ref) and np.array_equal(d.view(np.uint32), d_ref.view(np.uint32))
+    e2, intr2, PV2 = make_engine(rb, '640_480_color', pose=[0, -1.5, 0.75, 0, 0, 3.1], ds=2)     # looking away
+    d, ids = e2.render([0, 0, 0, 0, 0, 0], 6)
+    assert (ids == 255).all() and (d == 0).all()
+    tq = eng.pack_target(np.zeros((intr2.height, intr2.width)))
+    e2.set_target(tq, None, np.zeros(8, np.uint8))
+    err, sums, bi, _ = e2.eval(np.zeros((3, 6)), 6, eng.LOSS_DEPTH, want_sums=True)
+    assert (sums == 0).all() and np.isnan(err).all() and bi == 0
+
+
+def test_single_and_odd_candidate_counts(full):
+    rb, e, *_ = full
+    cand = helpers.slu_grid(rb.joint_limits, 16)
+    err_all, *_ = e.eval(cand, 4, eng.LOSS_FULL)
+    for sl in (slice(0, 1), slice(5, 6), slice(100, 1331)):
+        err, _, bi, be = e.eval(cand[sl], 4, eng.LOSS_FULL)
+        assert np.array_equal(err.view(np.uint64), err_all[sl].view(np.uint64))
+        assert be == err[bi] and bi == int(np.argmin(err))
+
+
+def test_abi_rejects_bad_calls():
+    rb = helpers.robot()
+    e = eng.Engine(0)
+    with pytest.raises(eng.EngineError):
+        e.upload_candidates(np.zeros((4, 6)))                      # robot/camera not set
+    e.set_robot(rb)
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    with pytest.raises(eng.EngineError):
+        e.set_camera(PV, 0, 10, ZNEAR, ZFAR)
+    e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+    e.upload_candidates(np.zeros((4, 6)))
+    with pytest.raises(eng.EngineError):
+        e.eval_resident(6, eng.LOSS_DEPTH)                         # no target yet
+    e.set_target(eng.pack_target(np.zeros((intr.height, intr.width))), None, np.zeros(8, np.uint8))
+    with pytest.raises(eng.EngineError):
+        e.eval_resident(7, eng.LOSS_DEPTH)                         # more links than the robot has
+    with pytest.raises(eng.EngineError):
+        e.eval_resident(6, eng.LOSS_LOOKUP, [0, 10, 0, 10])        # lookup loss needs the float32 plane
+    with pytest.raises(eng.EngineError):
+        e.upload_candidates(np.full((2, 6), np.nan))
+    with pytest.raises(ValueError):
+        e.set_target(np.zeros((3, 3), np.uint64))
+    e.eval_resident(6, eng.LOSS_DEPTH)                              # still usable after the refused calls
+    e.sync()
