@@ -159,7 +159,8 @@ def main():
                        "argmin_error": be, "argmin_index": bi},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "raster_score_kernel<DEPTH,SCORE>", "kernel_ms": kern['raster'],
+                         "kernel": "raster_score_kernel<DEPTH,SCORE> (+ its <DEPTH,LAYER> launch: links 0-2 once per distinct (S,L))",
+                         "kernel_ms": kern['raster'], "score_launch_ms": kern['score'], "layer_launch_ms": kern['layer'],
                          "bytes_per_candidate": B_CAND, "candidates_per_launch": C,
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
                                               "pass_total": kern['total']}},

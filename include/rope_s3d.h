@@ -102,8 +102,8 @@ int rope_coverage(rope_ctx *ctx, const double *cand, int C, int n_render, uint8_
 int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);
 
 /* Time `reps` back-to-back rope_eval_resident passes with HIP events on the context's
- * stream; ms[0] = FK kernel, ms[1] = raster+score kernel, ms[2] = finalize+argmin,
- * ms[3] = whole pass (averages per pass, milliseconds). */
+ * stream; ms[0] = FK + bounds kernels, ms[1] = shared-layer raster launch (0 when layers are not in use),
+ * ms[2] = raster+score launch, ms[3] = finalize+argmin, ms[4] = whole pass (averages per pass, milliseconds). */
 int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop, int reps, float *ms);
 
 /* Profiling aid, never used by the product path: bit mask of kernel phases to skip

@@ -371,7 +371,7 @@ static RasterArgs base_args(rope_ctx *c, int n_render)
 }
 
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
-                        hipEvent_t *ev /* 4 events or nullptr */)
+                        hipEvent_t *ev /* 5 events or nullptr */)
 {
     const bool layers = want_layers(c) && !(fp.debug & 128);
     const int n_shared = layers ? std::min(3, n_render) : 0;
@@ -390,11 +390,12 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
     a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss]; a.sums = c->d_sums;
-    HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+    HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err,
                                c->d_best_idx, c->d_best_err));
-    if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     c->last_n_render = n_render;
     return ROPE_OK;
 }
@@ -518,10 +519,10 @@ extern "C" int rope_profile_eval(rope_ctx *c, int n_render, int loss, const int3
     HIP_TRY(c, hipSetDevice(c->device));
     rc = ensure_empty(c, loss, fp);
     if (rc) return rc;
-    std::vector<hipEvent_t> ev(4 * (size_t)reps);
+    std::vector<hipEvent_t> ev(5 * (size_t)reps);
     for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
     for (int r = 0; r < reps; r++) {
-        rc = enqueue_eval(c, n_render, loss, fp, n_pix, &ev[4 * (size_t)r]);
+        rc = enqueue_eval(c, n_render, loss, fp, n_pix, &ev[5 * (size_t)r]);
         if (rc) break;
     }
     if (!rc) {
@@ -529,15 +530,15 @@ extern "C" int rope_profile_eval(rope_ctx *c, int n_render, int loss, const int3
         double acc[4] = {0, 0, 0, 0};
         for (int r = 0; r < reps; r++) {
             float t;
-            for (int k = 0; k < 3; k++) {
-                HIP_TRY(c, hipEventElapsedTime(&t, ev[4 * (size_t)r + k], ev[4 * (size_t)r + k + 1]));
+            for (int k = 0; k < 4; k++) {
+                HIP_TRY(c, hipEventElapsedTime(&t, ev[5 * (size_t)r + k], ev[5 * (size_t)r + k + 1]));
                 acc[k] += t;
             }
         }
         float total;
-        HIP_TRY(c, hipEventElapsedTime(&total, ev[0], ev[4 * (size_t)reps - 1]));
-        for (int k = 0; k < 3; k++) ms[k] = (float)(acc[k] / reps);
-        ms[3] = total / (float)reps;
+        HIP_TRY(c, hipEventElapsedTime(&total, ev[0], ev[5 * (size_t)reps - 1]));
+        for (int k = 0; k < 4; k++) ms[k] = (float)(acc[k] / reps);
+        ms[4] = total / (float)reps;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;

@@ -19,6 +19,9 @@ namespace rope {
 #ifndef ROPE_MIN_WAVES_PER_SIMD
 #define ROPE_MIN_WAVES_PER_SIMD 6
 #endif
+#ifndef ROPE_MIN_WAVES_FULL
+#define ROPE_MIN_WAVES_FULL 6               // measured: 6 waves with loss-pass spills beat 4 without (7.7 vs 8.4 ms)
+#endif
 constexpr int TILE_W = ROPE_TILE_W;
 constexpr int TILE_H = ROPE_TILE_H;
 constexpr int NWAVES = ROPE_NWAVES;       // waves per workgroup of the raster kernel

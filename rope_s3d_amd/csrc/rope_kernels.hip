@@ -135,17 +135,22 @@ struct Acc {
     uint64_t w[ROPE_SUM_WORDS];
 };
 
+// NEG subtracts instead of adds (modulo 2^64): lets "sums(tile) - sums(base)" live in one set of registers
+template <bool NEG>
+__device__ static inline void acc(uint64_t &w, uint64_t x) { if (NEG) w -= x; else w += x; }
+
+template <bool NEG>
 __device__ static inline void acc_sq(uint64_t *s, uint64_t dq)
 {
     uint32_t a = (uint32_t)(dq >> 20), b = (uint32_t)(dq & 0xFFFFFu);
-    s[SUM_S1] += dq;
-    s[SUM_AA] += (uint64_t)a * a;
-    s[SUM_AB] += (uint64_t)a * b;
-    s[SUM_BB] += (uint64_t)b * b;
+    acc<NEG>(s[SUM_S1], dq);
+    acc<NEG>(s[SUM_AA], (uint64_t)a * a);
+    acc<NEG>(s[SUM_AB], (uint64_t)a * b);
+    acc<NEG>(s[SUM_BB], (uint64_t)b * b);
 }
 
 // Loss terms of one pixel given its z-buffer key.  `pix` indexes the H x W target planes.
-template <int LOSS>
+template <int LOSS, bool NEG = false>
 __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t *__restrict__ tq,
                                           const float *__restrict__ t32, float c_num, float c_sum, float c_dif,
                                           uint64_t *s)
@@ -157,14 +162,14 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
         if (LOSS == ROPE_LOSS_TSWEEP) a = sqrtf(a);
         float diff = fabsf(a - sqrtf(z));
         uint64_t dq = q32_of_f32(diff);
-        if (dq) acc_sq(s, dq);
+        if (dq) acc_sq<NEG>(s, dq);
         return;
     }
     const uint64_t t = tq[pix];
     if (empty && t == 0) return;                  // nothing rendered, no target: every term is zero
     const uint64_t T = t & 0x7FFFFFFFFFull, zq = q32_of_f32(z);
     const uint64_t dq = T > zq ? T - zq : zq - T;
-    if (dq) { s[SUM_CNT] += 1; acc_sq(s, dq); }
+    if (dq) { acc<NEG>(s[SUM_CNT], 1); acc_sq<NEG>(s, dq); }
     if (LOSS == ROPE_LOSS_FULL) {
         const unsigned mask = (unsigned)(t >> 40) & 0xFFu;
         const int id = empty ? 255 : (int)(key & 0xFF);
@@ -174,8 +179,8 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
                 const bool M = (mask >> l) & 1, R = (id == l);
                 const uint64_t a = M ? T : 0, b = R ? zq : 0;
                 const uint64_t dl = a > b ? a - b : b - a;
-                s[SUM_LINK0 + 3 * l] += (uint64_t)(M != R);
-                if (dl) { s[SUM_LINK0 + 3 * l + 1] += 1; s[SUM_LINK0 + 3 * l + 2] += dl; }
+                acc<NEG>(s[SUM_LINK0 + 3 * l], (uint64_t)(M != R));
+                if (dl) { acc<NEG>(s[SUM_LINK0 + 3 * l + 1], 1); acc<NEG>(s[SUM_LINK0 + 3 * l + 2], dl); }
             }
         }
     }
@@ -196,9 +201,9 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
                                          int row0, int col0, const FrameParams &fp, int n_render,
                                          const uint64_t *__restrict__ tq, const float *__restrict__ t32, uint64_t *lds_sums)
 {
-    uint64_t s[ROPE_SUM_WORDS], e[ROPE_SUM_WORDS];
+    uint64_t s[ROPE_SUM_WORDS];
 #pragma unroll
-    for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = e[k] = 0;
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
     if (DELTA) {
         // only samples whose key differs from the base tile (the shared layer, or nothing) change the sums
         for (int i4 = threadIdx.x; i4 < TILE_W * TILE_H / 4; i4 += blockDim.x) {
@@ -212,8 +217,8 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
                 const int i = 4 * i4 + j, row = row0 + i / TILE_W, col = col0 + i % TILE_W;
                 if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
                 const size_t pix = (size_t)row * fp.W + col;
-                score_pixel<LOSS>(keys[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
-                score_pixel<LOSS>(bas[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, e);
+                score_pixel<LOSS, false>(keys[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+                score_pixel<LOSS, true>(bas[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
             }
         }
     } else {
@@ -226,8 +231,7 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) {
         const bool used = (LOSS == ROPE_LOSS_FULL) ? true : (k < SUM_LINK0);
-        const uint64_t d = s[k] - e[k];
-        if (used && d) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)d);
+        if (used && s[k]) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)s[k]);
     }
 }
 
@@ -444,7 +448,7 @@ __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
 template <int LOSS, int MODE>
-__global__ void __launch_bounds__(NTHREADS, ROPE_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(NTHREADS, LOSS == ROPE_LOSS_FULL ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
 raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 {
     const int n_render = ra.n_render;

@@ -202,8 +202,10 @@ class Engine:
         self._check(self._lib.rope_debug_skip(self._ctx, int(mask)), 'rope_debug_skip')
 
     def profile_eval(self, n_render: int, loss: int, crop=None, reps: int = 10):
-        """-> dict of average milliseconds per pass: fk, raster, finalize, total (HIP events on the engine stream)."""
+        """-> dict of average milliseconds per pass (HIP events on the engine stream): fk (+bounds), layer (shared
+        upstream links), score (per-candidate raster + loss), finalize (+argmin), total; raster = layer + score."""
         crop_a = np.ascontiguousarray(crop, np.int32) if crop is not None else None
-        ms = np.zeros(4, np.float32)
+        ms = np.zeros(5, np.float32)
         self._check(self._lib.rope_profile_eval(self._ctx, int(n_render), int(loss), _p(crop_a), int(reps), _p(ms)), 'rope_profile_eval')
-        return {'fk': float(ms[0]), 'raster': float(ms[1]), 'finalize': float(ms[2]), 'total': float(ms[3])}
+        return {'fk': float(ms[0]), 'layer': float(ms[1]), 'score': float(ms[2]), 'raster': float(ms[1] + ms[2]),
+                'finalize': float(ms[3]), 'total': float(ms[4])}

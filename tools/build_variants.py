@@ -4,10 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd import build
 VARIANTS = {
-    'base': '',
-    'h48_w6': '-DROPE_TILE_H=48 -DROPE_MIN_WAVES_PER_SIMD=6',
-    'h32_w6': '-DROPE_TILE_H=32 -DROPE_MIN_WAVES_PER_SIMD=6',
-    'h48': '-DROPE_TILE_H=48',
+    'full4': '',
+    'full6': '-DROPE_MIN_WAVES_FULL=6',
 }
 for name, flags in VARIANTS.items():
     os.environ['ROPE_HIPCC_EXTRA'] = flags
