@@ -37,6 +37,7 @@ constexpr int SMALL_TRI_ROWS = ROPE_SMALL_TRI_ROWS;   // boxes up to 4 samples w
 constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet list in LDS
 constexpr int MESHLET_MAX_VERTS = 128;
 constexpr int MESHLET_MAX_TRIS = 128;
+constexpr int COMPACT_PX = 60;            // meshlets no larger than this on screen take the 32-bit triangle set-up
 constexpr int MAX_MASK_WORDS = 256;        // tile-mask words per candidate (8192 tiles)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t D24_MAX = 16777215u;

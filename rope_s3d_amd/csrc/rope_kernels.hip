@@ -338,7 +338,9 @@ bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const 
                     y0 = (int)fmaxf(floorf(sylo - 1.5f), 0.0f); y1 = (int)fminf(ceilf(syhi + 0.5f), (float)(fp.H - 1));
                 }
                 if (x0 <= x1 && y0 <= y1) {
-                    bb = make_short4((short)x0, (short)x1, (short)y0, (short)y1);
+                    // bit 14 of x0: the meshlet's unclamped screen extent is at most COMPACT_PX both ways
+                    const bool compact = !behind && (sxhi - sxlo) <= (float)COMPACT_PX && (syhi - sylo) <= (float)COMPACT_PX;
+                    bb = make_short4((short)(x0 | (compact ? 0x4000 : 0)), (short)x1, (short)y0, (short)y1);
                     const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
                     const int ty0 = (fp.H - 1 - y1) / TILE_H, ty1 = (fp.H - 1 - y0) / TILE_H;
                     for (int ty = ty0; ty <= ty1; ty++)
@@ -384,23 +386,56 @@ __device__ static inline Edge make_edge(int32_t ax, int32_t ay, int32_t bx, int3
     return e;
 }
 
+// Same half-space for a triangle of a "compact" meshlet (screen extent <= COMPACT_PX in x and y, meeting this
+// tile): every coordinate difference is below 2^14 and every tile-relative vertex coordinate below 2^16, so the
+// products fit 32 bits and the operands 24 bits.  Algebraically identical to make_edge: with tile-relative
+// vertices the -A*col0 - B*vy0 term of K is a multiple of 256 inside Cc.
+__device__ static inline Edge make_edge_compact(int32_t ax, int32_t ay, int32_t bx, int32_t by, const TileFrame &tf)
+{
+    Edge e;
+    e.A = -(by - ay);
+    e.B = bx - ax;
+    const int32_t rx = ax - 256 * tf.col0, ry = ay - 256 * tf.vy0;
+    const int32_t Cc = 128 * (e.A + e.B) - __mul24(e.A, rx) - __mul24(e.B, ry) + (owns(ax, ay, bx, by) ? 0 : -1);
+    e.K = -(Cc >> 8);
+    return e;
+}
+
+__device__ static inline int32_t edge_fn_compact(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t fx, int32_t fy)
+{
+    return __mul24(bx - ax, fy - ay) - __mul24(by - ay, fx - ax);
+}
+
 // Window-depth plane of a front-facing triangle, anchored at the pixel that holds vertex a.
 struct Plane { float gx, gy, dc; };
 
-__device__ static inline Plane make_plane(const SVert &a, const SVert &b, const SVert &c, int64_t area2)
+// depth plane from the float32 images of area2 and of the two edge functions at the anchor
+__device__ static inline Plane plane_from(const SVert &a, const SVert &b, const SVert &c, float area_f, float E20a_f, float E01a_f)
 {
-    const int32_t pxa = a.X >> 8, pya = a.Y >> 8;
-    const int32_t fxa = pxa * 256 + 128, fya = pya * 256 + 128;
-    const int64_t E20a = edge_fn(c.X, c.Y, a.X, a.Y, fxa, fya), E01a = edge_fn(a.X, a.Y, b.X, b.Y, fxa, fya);
-    const float inv = 1.0f / (float)(double)area2;
+    const float inv = 1.0f / area_f;
     const float e1 = b.d - a.d, e2 = c.d - a.d;
     const float fA20 = (float)(-(a.Y - c.Y)), fB20 = (float)(a.X - c.X);
     const float fA01 = (float)(-(b.Y - a.Y)), fB01 = (float)(b.X - a.X);
     Plane p;
     p.gx = (((e1 * fA20) + (e2 * fA01)) * inv) * 256.0f;
     p.gy = (((e1 * fB20) + (e2 * fB01)) * inv) * 256.0f;
-    p.dc = a.d + (((e1 * (float)(double)E20a) + (e2 * (float)(double)E01a)) * inv);
+    p.dc = a.d + (((e1 * E20a_f) + (e2 * E01a_f)) * inv);
     return p;
+}
+
+// compact meshlets: the integers fit 32 bits, and (float)(double)x == (float)x for a 32-bit integer x
+__device__ static inline Plane make_plane_compact(const SVert &a, const SVert &b, const SVert &c, int32_t area2)
+{
+    const int32_t fxa = (a.X >> 8) * 256 + 128, fya = (a.Y >> 8) * 256 + 128;
+    return plane_from(a, b, c, (float)area2, (float)edge_fn_compact(c.X, c.Y, a.X, a.Y, fxa, fya),
+                      (float)edge_fn_compact(a.X, a.Y, b.X, b.Y, fxa, fya));
+}
+
+__device__ static inline Plane make_plane(const SVert &a, const SVert &b, const SVert &c, int64_t area2)
+{
+    const int32_t fxa = (a.X >> 8) * 256 + 128, fya = (a.Y >> 8) * 256 + 128;
+    const int64_t E20a = edge_fn(c.X, c.Y, a.X, a.Y, fxa, fya), E01a = edge_fn(a.X, a.Y, b.X, b.Y, fxa, fya);
+    return plane_from(a, b, c, (float)(double)area2, (float)(double)E20a, (float)(double)E01a);
 }
 
 __device__ static inline void depth_test_write(uint32_t *tile, int u, int v, const Plane &pl, float dx, float dy, uint32_t link)
@@ -501,9 +536,10 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
         for (int m = m_begin + tid; m < m_end; m += NTHREADS) {
             const short4 b = bb[m];
-            if (b.x <= b.y && b.x <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
+            const int bx0 = b.x & 0x3FFF;
+            if (bx0 <= b.y && bx0 <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
                 int pos = atomicAdd(&s_count, 1);
-                s_list[pos] = (uint16_t)m;
+                s_list[pos] = (uint16_t)(m | ((b.x & 0x4000) ? 0x8000 : 0));
             }
         }
     }
@@ -535,7 +571,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         if (lane == 0) li = atomicAdd(&s_next, 1);
         li = __builtin_amdgcn_readfirstlane(li);
         if (li >= n_list) break;
-        const int m = s_list[li];
+        const int m_entry = __builtin_amdgcn_readfirstlane((int)s_list[li]);
+        const int m = m_entry & 0x7FFF;
+        const bool compact = (m_entry & 0x8000) != 0;     // wave-uniform: chooses the 32-bit set-up
         const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
         const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
         const uint32_t l = h1.w;
@@ -567,12 +605,14 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 packed = rp.ml_tris[t0 + t];
                 const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
                 if (a.X != SV_BAD && b.X != SV_BAD && c.X != SV_BAD) {
-                    const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
+                    bool front;
+                    if (compact) front = __mul24(b.X - a.X, c.Y - a.Y) - __mul24(c.X - a.X, b.Y - a.Y) > 0;
+                    else front = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y) > 0;
                     const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
                     const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
                     const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
                     const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
-                    keep = area2 > 0 && x0 <= x1 && y0 <= y1;
+                    keep = front && x0 <= x1 && y0 <= y1;
                 }
             }
             const unsigned long long km = __ballot(keep);
@@ -595,17 +635,27 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 const uint32_t packed = wkeep[t];
                 const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
                 {
-                    const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
                     const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
                     const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
                     const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
                     const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
                     {
-                        const Plane pl = make_plane(a, b, c, area2);
+                        Plane pl;
+                        Edge e0, e1, e2;
+                        int32_t big = 0;
+                        if (compact) {
+                            pl = make_plane_compact(a, b, c, __mul24(b.X - a.X, c.Y - a.Y) - __mul24(c.X - a.X, b.Y - a.Y));
+                            e0 = make_edge_compact(a.X, a.Y, b.X, b.Y, tf);
+                            e1 = make_edge_compact(b.X, b.Y, c.X, c.Y, tf);
+                            e2 = make_edge_compact(c.X, c.Y, a.X, a.Y, tf);
+                        } else {
+                            pl = make_plane(a, b, c, (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y));
+                            e0 = make_edge(a.X, a.Y, b.X, b.Y, tf);
+                            e1 = make_edge(b.X, b.Y, c.X, c.Y, tf);
+                            e2 = make_edge(c.X, c.Y, a.X, a.Y, tf);
+                            big = max(max(abs(e0.A), abs(e0.B)), max(max(abs(e1.A), abs(e1.B)), max(abs(e2.A), abs(e2.B))));
+                        }
                         const int32_t pxa = a.X >> 8, pya = a.Y >> 8;
-                        const Edge e0 = make_edge(a.X, a.Y, b.X, b.Y, tf), e1 = make_edge(b.X, b.Y, c.X, c.Y, tf),
-                                   e2 = make_edge(c.X, c.Y, a.X, a.Y, tf);
-                        const int32_t big = max(max(abs(e0.A), abs(e0.B)), max(max(abs(e1.A), abs(e1.B)), max(abs(e2.A), abs(e2.B))));
                         const int w = x1 - x0 + 1, h = y1 - y0 + 1;
                         if (big >= EDGE_COEF_LIMIT) {
                             // enormous triangle (edge extent >= 16384 px): exact 64-bit walk, one lane
