@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""End-to-end frames/s of the whole prediction pipeline on synthetic frames (BASELINE configs[2]-like, without the
+Mask R-CNN stage: link masks come from the colour-coded render, as the reference's SyntheticPredictor does).
+
+    python tools/bench_frames.py [n_frames] [ds_factor] [base_intrin] [lookup_divisions]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
+from rope_s3d_amd import SyntheticPredictor
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
+from rope_s3d_amd.prediction.analysis import joint_error_stats
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+ds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+intr = sys.argv[3] if len(sys.argv) > 3 else '1280_720_color'
+div = int(sys.argv[4]) if len(sys.argv) > 4 else None
+sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, intr, ds, 'SLU', noise=False, seed=1, lookup_divisions=div)
+p = sp.predictor
+print(f"render {p.intrinsics.width}x{p.intrinsics.height}, lookup grid {len(p.lookup_angles)} poses, crop {list(p.lookup_crop)}")
+lim = sp.urdf_reader.joint_limits
+poses = [np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]) for f in range(n)]
+sp.run(poses[0])                                   # warm-up
+p.evaluations = 0
+res = np.zeros((2, n, 6))
+t0 = time.perf_counter()
+for f in range(n):
+    res[0, f], res[1, f] = sp.run(poses[f])
+dt = time.perf_counter() - t0
+st = joint_error_stats(res[1], res[0])
+print(f"{n} frames in {dt:.2f} s = {n / dt:.1f} frames/s, {p.evaluations / n:.0f} candidate evaluations/frame, "
+      f"{p.evaluations / dt:.0f} poses/s end to end (includes host-side frame synthesis)")
+print("joint-angle |error| mean (rad) S,L,U:", np.round(st['mean'][:3], 5), " p95:", np.round(st['p95'][:3], 5), " max:", np.round(st['max'][:3], 5))
