@@ -90,6 +90,15 @@ int rope_results_download(rope_ctx *ctx, double *err_out, uint64_t *sums_out, in
 int rope_eval(rope_ctx *ctx, const double *cand, int C, int n_render, int loss, const int32_t *crop,
               double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err);
 
+/* Stored lookup table.  rope_lookup_build renders the pose grid once (first n_render links) and keeps the
+ * cropped sqrt-depth images in HBM (C x crop_h x crop_w float32); rope_lookup_score streams the table against
+ * the current target's float32 plane and returns the lookup score of every row and the first argmin.
+ * Replaces RobotLookupCreator.run / RobotLookupManager.get (lookup.py:69-106,184-283), tf.pow(depth, 0.5)
+ * (predict.py:117) and the TF reduction + argmin per frame (predict.py:167-171).  Scores are bit-identical to
+ * rope_eval with ROPE_LOSS_LOOKUP on the same grid and crop. */
+int rope_lookup_build(rope_ctx *ctx, const double *cand, int C, int n_render, const int32_t *crop);
+int rope_lookup_score(rope_ctx *ctx, double *scores_out, int32_t *best_idx, double *best_score);
+
 /* One pose to images.  Replaces Renderer.setJointAngles + Renderer.render (render.py:88-98).
  *   depth H x W float32 metres (0 = empty), ids H x W uint8 link id (255 = background) */
 int rope_render(rope_ctx *ctx, const double *q, int n_render, float *depth, uint8_t *ids);

@@ -63,6 +63,12 @@ struct rope_ctx {
     int32_t *d_best_idx = nullptr;
     int last_n_render = 0;
 
+    // stored lookup table (cropped sqrt-depth of a pose grid)
+    float *d_table = nullptr;
+    size_t table_cap = 0;
+    int table_C = 0, table_crop[4] = {0, 0, 0, 0};
+    uint64_t *d_zero_total = nullptr;
+
     // single-pose render scratch
     uint32_t *d_key = nullptr;
     float *d_depth = nullptr;
@@ -129,7 +135,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_table, c->d_zero_total, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -200,6 +206,7 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
     c->rp.n_meshlets = n_meshlets;
     c->cap = 0;                                   // per-candidate buffers depend on the meshlet count
     c->C = 0;
+    c->table_C = 0;
     c->n_links = n_links;
     c->n_meshlets = n_meshlets;
     c->have_robot = true;
@@ -225,6 +232,7 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
     c->n_tiles = c->fp.tiles_x * c->fp.tiles_y;
     if ((c->n_tiles + 31) / 32 > MAX_MASK_WORDS) ARG_FAIL(c, "rope_set_camera: too many tiles");
     if ((c->n_tiles + 31) / 32 != c->mask_words) { c->mask_words = (c->n_tiles + 31) / 32; c->cap = 0; c->C = 0; }
+    c->table_C = 0;                               // a stored lookup table belongs to one camera
     HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
     if (resized) {
         size_t n = (size_t)W * H;
@@ -486,6 +494,71 @@ extern "C" int rope_coverage(rope_ctx *c, const double *cand, int C, int n_rende
     int rc = raster_only(c, cand, C, n_render, MODE_COVER);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(cover, c->d_cover, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ROPE_OK;
+}
+
+extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_render, const int32_t *crop)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!cand || !crop) ARG_FAIL(c, "rope_lookup_build: null pointer");
+    if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "rope_lookup_build: robot and camera must be set first");
+    if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "rope_lookup_build: n_render out of range");
+    if (crop[0] < 0 || crop[1] >= c->fp.H || crop[0] > crop[1] || crop[2] < 0 || crop[3] >= c->fp.W || crop[2] > crop[3])
+        ARG_FAIL(c, "rope_lookup_build: crop outside the image");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = rope_candidates_upload(c, cand, C);
+    if (rc) return rc;
+    const size_t px = (size_t)(crop[1] - crop[0] + 1) * (size_t)(crop[3] - crop[2] + 1), need = px * (size_t)C;
+    if (need > c->table_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, realloc_dev(&c->d_table, need));
+        c->table_cap = need;
+    }
+    if (!c->d_zero_total) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_zero_total, ROPE_SUM_WORDS * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemset(c->d_zero_total, 0, ROPE_SUM_WORDS * sizeof(uint64_t)));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_table, 0, need * sizeof(float), c->stream));
+    FrameParams fp = c->fp;
+    fp.r0 = crop[0]; fp.r1 = crop[1]; fp.c0 = crop[2]; fp.c1 = crop[3];
+    const bool layers = want_layers(c);
+    const int n_shared = layers ? std::min(3, n_render) : 0;
+    if (layers) { rc = ensure_layers(c); if (rc) return rc; }
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp));
+    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    RasterArgs a = base_args(c, n_render);
+    if (layers) {
+        // layer pass without loss sums (layer_sums == nullptr): no target is needed to build a table
+        RasterArgs la = a;
+        la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
+        HIP_TRY(c, launch_raster(MODE_LAYER, ROPE_LOSS_DEPTH, c->n_layers, c->stream, c->fp, c->rp, la));
+        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers;
+    }
+    a.table = c->d_table;
+    HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->table_C = C;
+    std::memcpy(c->table_crop, crop, 4 * sizeof(int32_t));
+    return ROPE_OK;
+}
+
+extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_idx, double *best_score)
+{
+    if (!c) return ROPE_E_ARG;
+    if (c->table_C < 1) ARG_FAIL(c, "rope_lookup_score: no table built");
+    if (!c->have_target || !c->have_t32) ARG_FAIL(c, "rope_lookup_score: needs a target with the float32 plane");
+    if (c->table_C > c->cap) ARG_FAIL(c, "rope_lookup_score: result buffers were resized; rebuild the table");
+    HIP_TRY(c, hipSetDevice(c->device));
+    FrameParams fp = c->fp;
+    fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
+    const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
+    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_sums));
+    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf,
+                               c->d_err, c->d_best_idx, c->d_best_err));
+    if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_err, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (best_idx) HIP_TRY(c, hipMemcpyAsync(best_idx, c->d_best_idx, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (best_score) HIP_TRY(c, hipMemcpyAsync(best_score, c->d_best_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ROPE_OK;
 }

@@ -46,7 +46,7 @@ constexpr uint32_t D24_MAX = 16777215u;
 enum { SUM_CNT = 0, SUM_S1 = 1, SUM_AA = 2, SUM_AB = 3, SUM_BB = 4, SUM_LINK0 = 5 };
 static_assert(SUM_LINK0 + 3 * ROPE_MAX_LINKS == ROPE_SUM_WORDS, "sum layout");
 
-enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3 };
+enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3, MODE_TABLE = 4 };
 
 struct FrameParams {
     int W, H, tiles_x, tiles_y;
@@ -81,6 +81,7 @@ struct RasterArgs {
     uint64_t *layer_sums;                 // n_layers x n_tiles x ROPE_SUM_WORDS: loss sums of the layer alone
     const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
     uint64_t *sums; uint32_t *key_out; uint8_t *cover;
+    float *table;                         // MODE_TABLE: C x crop_h x crop_w sqrt-depth (crop = fp.r0..c1)
 };
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
@@ -94,6 +95,8 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
                         uint64_t *empty_sums, uint64_t *total);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err, int32_t *best_idx, double *best_err);
+// score every row of a stored lookup table against the float32 target plane
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, uint64_t *sums);
 hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);
 
 }  // namespace rope

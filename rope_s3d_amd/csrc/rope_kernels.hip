@@ -545,7 +545,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     }
     __syncthreads();
     const int n_list = s_count;
-    if (n_list == 0 && MODE != MODE_LAYER) {
+    if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile)) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
         if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
             const uint64_t d = ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
@@ -758,9 +758,23 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         uint4 *dst = reinterpret_cast<uint4 *>(ra.layers + slot * (TILE_W * TILE_H));
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) dst[i] = reinterpret_cast<const uint4 *>(tile)[i];
         // loss sums of the layer alone (relative to "nothing rendered"): every candidate on this layer starts from them
-        score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, lds_sums);
-        __syncthreads();
-        if (tid < ROPE_SUM_WORDS) ra.layer_sums[slot * ROPE_SUM_WORDS + tid] = lds_sums[tid];
+        if (ra.layer_sums) {
+            score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, lds_sums);
+            __syncthreads();
+            if (tid < ROPE_SUM_WORDS) ra.layer_sums[slot * ROPE_SUM_WORDS + tid] = lds_sums[tid];
+        }
+        return;
+    }
+    if (MODE == MODE_TABLE) {
+        // one row of the lookup table: sqrt of the metric depth over the crop (predict.py:117 sqrt of the table,
+        // lookup.py:92 crop); samples nothing was drawn on stay 0 from the table's memset
+        const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
+        float *dst = ra.table + (size_t)cand * cw * ch;
+        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) {
+            const int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
+            if (tile[i] == KEY_EMPTY || !pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
+            dst[(size_t)(row - fp.r0) * cw + (col - fp.c0)] = sqrtf(linear_depth(tile[i] >> 8, fp.c_num, fp.c_sum, fp.c_dif));
+        }
         return;
     }
     if (MODE == MODE_DUMP) {
@@ -784,6 +798,41 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         uint64_t delta = lds_sums[tid];
         if (layer_tile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
         if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
+    }
+}
+
+// ------------------------------------------------------------- lookup table -----
+// Lookup stage against a stored table (predict.py:165-171): per row k of the table,
+// the exact sums of |T - sqrtD_k| in Q32 over the crop.  Pure streaming: N*h*w*4 bytes read once.
+__global__ void __launch_bounds__(256)
+table_score_kernel(FrameParams fp, const float *__restrict__ table, const float *__restrict__ t32, uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t lds[4];
+    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1, n = cw * ch;
+    const float *row = table + (size_t)blockIdx.x * n;
+    if (threadIdx.x < 4) lds[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t s[ROPE_SUM_WORDS];
+    s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i / cw, c = i - r * cw;
+        const float t = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
+        const uint64_t dq = q32_of_f32(fabsf(t - row[i]));
+        if (dq) acc_sq<false>(s, dq);
+    }
+    const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t v = s[words[k]];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds[k], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (threadIdx.x < ROPE_SUM_WORDS) {
+        uint64_t v = 0;
+        for (int k = 0; k < 4; k++) if ((int)threadIdx.x == words[k]) v = lds[k];
+        sums[(size_t)blockIdx.x * ROPE_SUM_WORDS + threadIdx.x] = v;
     }
 }
 
@@ -909,6 +958,7 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
     dim3 grid(fp.tiles_x * fp.tiles_y, rows);
     if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a);
     else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a);
+    else if (mode == MODE_TABLE) launch_one<ROPE_LOSS_LOOKUP, MODE_TABLE>(grid, st, fp, rp, a);
     else if (mode == MODE_LAYER) {
         if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a);
         else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a);
@@ -941,6 +991,12 @@ hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total
 {
     hipLaunchKernelGGL(finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, total_empty, C, loss, n_render, n_pix, lf, err);
     hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, st, err, C, best_idx, best_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, uint64_t *sums)
+{
+    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, fp, table, t32, sums);
     return hipGetLastError();
 }
 

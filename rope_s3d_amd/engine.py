@@ -20,7 +20,7 @@ TQ_MAX = (1 << 39) - 1
 ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
-    'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip')
+    'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip')
 
 
 class EngineUnavailable(RuntimeError):
@@ -61,6 +61,8 @@ def load_library(path: str = None):
     lib.rope_sync.argtypes = [vp]
     lib.rope_results_download.argtypes = [vp, vp, vp, vp, vp]
     lib.rope_eval.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.rope_lookup_build.argtypes = [vp, vp, i32, i32, vp]
+    lib.rope_lookup_score.argtypes = [vp, vp, vp, vp]
     lib.rope_render.argtypes = [vp, vp, i32, vp, vp]
     lib.rope_coverage.argtypes = [vp, vp, i32, i32, vp]
     lib.rope_debug_mvp.argtypes = [vp, vp, i32, i32]
@@ -177,6 +179,21 @@ class Engine:
         self.upload_candidates(cand)
         self.eval_resident(n_render, loss, crop)
         return self.download(True, want_sums)
+
+    def lookup_build(self, cand, n_render: int, crop):
+        """Render the pose grid once into an HBM-resident table of cropped sqrt-depth images."""
+        cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
+        crop_a = np.ascontiguousarray(crop, np.int32)
+        self._check(self._lib.rope_lookup_build(self._ctx, _p(cand), len(cand), int(n_render), _p(crop_a)), 'rope_lookup_build')
+        self.n_candidates = len(cand)
+        self._table_rows = len(cand)
+
+    def lookup_score(self, want_scores: bool = False):
+        """-> (scores or None, first-argmin row, its score) of the stored table against the current target."""
+        scores = np.empty(self._table_rows, np.float64) if want_scores else None
+        bi, be = C.c_int32(), C.c_double()
+        self._check(self._lib.rope_lookup_score(self._ctx, _p(scores), C.byref(bi), C.byref(be)), 'rope_lookup_score')
+        return scores, int(bi.value), float(be.value)
 
     def render(self, q, n_render: int = 6):
         """-> (depth float32 HxW metres, link id uint8 HxW with 255 = background)."""

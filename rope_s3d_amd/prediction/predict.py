@@ -70,7 +70,8 @@ class Predictor:
                  *,
                  device: int = 0,
                  segmenter: Optional[Callable] = None,
-                 lookup_divisions=None):
+                 lookup_divisions=None,
+                 lookup_table_budget: int = 32 << 30):
         """Reference parameters as in predict.py:38-70.  Extra keyword-only arguments:
 
         device            HIP device ordinal of the engine context
@@ -78,6 +79,8 @@ class Predictor:
                           stands in for pixellib's segmentImage (predict.py:416) when color_dict is None
         lookup_divisions  explicit lookup grid divisions (six ints or one int for every lookup joint);
                           default: the reference's size rule with an 8 GiB budget (simulation/lookup.py)
+        lookup_table_budget  bytes of HBM the stored lookup table may take (default 32 GiB); larger grids are
+                          rendered and scored on the fly every frame instead
         """
         if preview:
             raise NotImplementedError("preview needs an OpenCV window (ProjectionViz, predict.py:517-602): out of scope")
@@ -102,6 +105,7 @@ class Predictor:
             self.seg = segmenter
             self.model_ds = model_ds
         self._lookup_divisions = lookup_divisions
+        self.lookup_table_budget = int(lookup_table_budget)
         self.camera_pose = None
         self.changeCameraPose(camera_pose)
         self.evaluations = 0          # candidates rendered+scored, for throughput accounting
@@ -123,6 +127,14 @@ class Predictor:
             div = d
         self.lookup_angles, _ = lm.get(self.crops.size(LOOKUP_NUM_RENDERED), LOOKUP_JOINTS, divisions=div)
         self.lookup_crop = np.asarray(self.crops[LOOKUP_NUM_RENDERED], dtype=np.int32)
+        # The reference keeps the grid as a table of cropped depth images (lookup.py:92-106) and takes its square
+        # root once (predict.py:117).  Same here, in HBM, when it fits the budget; otherwise every frame renders
+        # and scores the grid on the fly (identical scores either way).
+        c = self.lookup_crop
+        table_bytes = len(self.lookup_angles) * int(c[1] - c[0] + 1) * int(c[3] - c[2] + 1) * 4
+        self._lookup_table = table_bytes <= self.lookup_table_budget
+        if self._lookup_table:
+            self.engine.lookup_build(self.lookup_angles, LOOKUP_NUM_RENDERED, self.lookup_crop)
 
     def _setStages(self):
         self.stages = getStages(self.do_angles)
@@ -253,7 +265,10 @@ class Predictor:
     def _stage_lookup(self):
         """argmin over the pose grid of mean|T - sqrt(D_k)| * std|T - sqrt(D_k)| on the crop, T not
         sqrt-ed (predict.py:165-171).  The grid is rendered and scored on the device."""
-        _, _, best, _ = self.engine.eval(self.lookup_angles, LOOKUP_NUM_RENDERED, LOSS_LOOKUP, crop=self.lookup_crop)
+        if self._lookup_table:
+            _, best, _ = self.engine.lookup_score()               # stream the stored table (HBM-bound)
+        else:
+            _, _, best, _ = self.engine.eval(self.lookup_angles, LOOKUP_NUM_RENDERED, LOSS_LOOKUP, crop=self.lookup_crop)
         self.evaluations += len(self.lookup_angles)
         # .copy(): the reference returns a row VIEW of its angle table (predict.py:171), which the Descent
         # stage then edits in place (predict.py:213), so its table drifts from frame to frame.  Frames stay

@@ -89,3 +89,24 @@ def test_shared_layers_do_not_change_results(scene):
         assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
         err_ref = o.eval(cand[::7], loss, n, tq, t32, None, flags, threads=8)
         assert np.array_equal(err_a[::7].view(np.uint64), err_ref.view(np.uint64))
+
+
+def test_stored_lookup_table_scores_equal_on_the_fly(scene):
+    """rope_lookup_build + rope_lookup_score == rope_eval(LOSS_LOOKUP) == oracle, bit for bit, also after the
+    candidate buffers were reused by other evaluations in between."""
+    rb, intr, PV, o, e = scene
+    cand = helpers.slu_grid(rb.joint_limits, 5)
+    crop = [150, 479, 200, 600]
+    e.lookup_build(cand, 6, crop)
+    for q in ([0.35, 0.45, 0.9, 0, 0, 0], [1.0, -0.3, 1.7, 0, 0, 0]):
+        d, ids = o.render(q)
+        tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+        e.set_target(tq, t32, flags)
+        scores, bi, be = e.lookup_score(want_scores=True)
+        err, _, bi2, be2 = e.eval(cand[:7], 6, eng.LOSS_FULL)         # something else uses the context in between
+        err_fly, _, bi_fly, be_fly = e.eval(cand, 6, eng.LOSS_LOOKUP, crop)
+        assert np.array_equal(scores.view(np.uint64), err_fly.view(np.uint64)) and bi == bi_fly and be == be_fly
+        ref = o.eval(cand[::5], orc.LOSS_LOOKUP, 6, tq, t32, crop, flags, threads=8)
+        assert np.array_equal(scores[::5].view(np.uint64), ref.view(np.uint64))
+        scores2, bi3, _ = e.lookup_score(want_scores=True)             # table survives the other launches
+        assert np.array_equal(scores2.view(np.uint64), scores.view(np.uint64)) and bi3 == bi
