@@ -48,6 +48,7 @@ struct rope_ctx {
     // candidates + results
     int C = 0, cap = 0;
     double *d_cand = nullptr, *d_err = nullptr, *d_best_err = nullptr;
+    double *h_stage = nullptr;             // pinned staging: candidates up, errors + best down
     float *d_mvp = nullptr;
     short4 *d_bounds = nullptr;
     uint32_t *d_mask_lo = nullptr, *d_mask_hi = nullptr;
@@ -140,6 +141,7 @@ extern "C" void rope_destroy(rope_ctx *c)
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -276,7 +278,9 @@ static int ensure_capacity(rope_ctx *c, int C)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     int cap = C < 64 ? 64 : C;
     HIP_TRY(c, realloc_dev(&c->d_cand, 6 * (size_t)cap));
-    HIP_TRY(c, realloc_dev(&c->d_err, (size_t)cap));
+    HIP_TRY(c, realloc_dev(&c->d_err, (size_t)cap + 2));      // errors, then best error and best index
+    if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; }
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, ((size_t)cap * 6 + 2) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(c, realloc_dev(&c->d_mvp, (size_t)cap * ROPE_MAX_LINKS * 16));
     if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "candidates: robot and camera must be set first");
     HIP_TRY(c, realloc_dev(&c->d_bounds, (size_t)cap * c->n_meshlets));
@@ -297,31 +301,38 @@ extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_capacity(c, C);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_cand, cand, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the staging buffer may still feed an earlier copy
+    std::memcpy(c->h_stage, cand, 6 * (size_t)C * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cand, c->h_stage, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
     // group candidates whose first two joint angles are bit-identical: their base_link, link_1_s and
     // link_2_l transforms are the same bits, so those links are rasterised once per group (a "layer")
-    struct Key { uint64_t a, b; int idx; };
-    std::vector<Key> keys((size_t)C);
-    for (int i = 0; i < C; i++) {
-        std::memcpy(&keys[i].a, &cand[6 * (size_t)i], 8);
-        std::memcpy(&keys[i].b, &cand[6 * (size_t)i + 1], 8);
-        keys[i].idx = i;
+    c->n_layers = C;                               // "no sharing" unless the grouping below finds some
+    if (C >= 8) {
+        struct Key { uint64_t a, b; int idx; };
+        std::vector<Key> keys((size_t)C);
+        for (int i = 0; i < C; i++) {
+            std::memcpy(&keys[i].a, &cand[6 * (size_t)i], 8);
+            std::memcpy(&keys[i].b, &cand[6 * (size_t)i + 1], 8);
+            keys[i].idx = i;
+        }
+        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.idx < y.idx); });
+        std::vector<int32_t> layer_of((size_t)C), layer_rep;
+        for (int i = 0; i < C; i++) {
+            if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) layer_rep.push_back(keys[i].idx);
+            layer_of[keys[i].idx] = (int32_t)layer_rep.size() - 1;
+        }
+        c->n_layers = (int)layer_rep.size();
+        if (c->n_layers * 4 <= C) {                // same rule as want_layers(): only then are the arrays read
+            if (c->n_layers > c->layer_rep_cap) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, realloc_dev(&c->d_layer_rep, (size_t)c->n_layers));
+                c->layer_rep_cap = c->n_layers;
+            }
+            HIP_TRY(c, hipMemcpyAsync(c->d_layer_of, layer_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_layer_rep, layer_rep.data(), layer_rep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));   // layer_of / layer_rep are stack-local
+        }
     }
-    std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.idx < y.idx); });
-    std::vector<int32_t> layer_of((size_t)C), layer_rep;
-    for (int i = 0; i < C; i++) {
-        if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) layer_rep.push_back(keys[i].idx);
-        layer_of[keys[i].idx] = (int32_t)layer_rep.size() - 1;
-    }
-    c->n_layers = (int)layer_rep.size();
-    if (c->n_layers > c->layer_rep_cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, realloc_dev(&c->d_layer_rep, (size_t)c->n_layers));
-        c->layer_rep_cap = c->n_layers;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->d_layer_of, layer_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_layer_rep, layer_rep.data(), layer_rep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller
     c->C = C;
     return ROPE_OK;
 }
@@ -385,9 +396,8 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
-    HIP_TRY(c, hipMemsetAsync(c->d_sums, 0, (size_t)c->C * ROPE_SUM_WORDS * sizeof(uint64_t), c->stream));
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     RasterArgs a = base_args(c, n_render);
     if (layers) {
@@ -401,8 +411,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err,
-                               c->d_best_idx, c->d_best_err));
+    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err));
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     c->last_n_render = n_render;
     return ROPE_OK;
@@ -433,11 +442,13 @@ extern "C" int rope_results_download(rope_ctx *c, double *err_out, uint64_t *sum
     if (!c) return ROPE_E_ARG;
     if (c->C < 1) ARG_FAIL(c, "rope_results_download: nothing evaluated");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (err_out) HIP_TRY(c, hipMemcpyAsync(err_out, c->d_err, (size_t)c->C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // one copy brings the errors, the best error and the best index (pinned staging)
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err, ((size_t)c->C + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (sums_out) HIP_TRY(c, hipMemcpyAsync(sums_out, c->d_sums, (size_t)c->C * ROPE_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    if (best_idx) HIP_TRY(c, hipMemcpyAsync(best_idx, c->d_best_idx, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (best_err) HIP_TRY(c, hipMemcpyAsync(best_err, c->d_best_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (err_out) std::memcpy(err_out, c->h_stage, (size_t)c->C * sizeof(double));
+    if (best_err) *best_err = c->h_stage[c->C];
+    if (best_idx) *best_idx = (int32_t)c->h_stage[c->C + 1];
     return ROPE_OK;
 }
 
@@ -457,7 +468,7 @@ static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "render: n_render out of range");
     int rc = rope_candidates_upload(c, cand, C);
     if (rc) return rc;
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, c->fp, c->rp, n_render, 0, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     RasterArgs a = base_args(c, n_render);
     a.key_out = c->d_key; a.cover = c->d_cover;
@@ -525,7 +536,7 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
     const bool layers = want_layers(c);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { rc = ensure_layers(c); if (rc) return rc; }
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     RasterArgs a = base_args(c, n_render);
     if (layers) {
@@ -554,12 +565,12 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
     HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_sums));
-    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf,
-                               c->d_err, c->d_best_idx, c->d_best_err));
+    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_err));
     if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_err, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (best_idx) HIP_TRY(c, hipMemcpyAsync(best_idx, c->d_best_idx, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (best_score) HIP_TRY(c, hipMemcpyAsync(best_score, c->d_best_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err + c->table_C, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (best_score) *best_score = c->h_stage[0];
+    if (best_idx) *best_idx = (int32_t)c->h_stage[1];
     return ROPE_OK;
 }
 

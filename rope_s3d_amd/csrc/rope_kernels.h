@@ -85,7 +85,8 @@ struct RasterArgs {
 };
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
-                     const double *joint_axes, const double *PV, float *mvp);
+                     const double *joint_axes, const double *PV, float *mvp, uint64_t *sums, uint32_t *mask_lo,
+                     uint32_t *mask_hi, int mask_words);
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
@@ -94,7 +95,7 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,
                         uint64_t *empty_sums, uint64_t *total);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
-                           double n_pix, const LinkFlags &lf, double *err, int32_t *best_idx, double *best_err);
+                           double n_pix, const LinkFlags &lf, double *err /* C + 2: errors, best error, best index */);
 // score every row of a stored lookup table against the float32 target plane
 hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, uint64_t *sums);
 hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);

@@ -77,10 +77,14 @@ __device__ static inline void aff_mul(const double *A, const double *B, double *
 // One thread per candidate.  Writes n_render 4x4 float matrices.
 __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
-              const double *__restrict__ joint_axes, const double *__restrict__ PV, float *__restrict__ mvp)
+              const double *__restrict__ joint_axes, const double *__restrict__ PV, float *__restrict__ mvp,
+              uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    // first kernel of a pass: clear what the later kernels accumulate into (saves three memset launches)
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) sums[(size_t)c * ROPE_SUM_WORDS + k] = 0;
+    for (int k = 0; k < mask_words; k++) { mask_lo[(size_t)c * mask_words + k] = 0; mask_hi[(size_t)c * mask_words + k] = 0; }
     double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (int l = 0; l < n_render; l++) {
         if (l > 0) {
@@ -847,12 +851,10 @@ __device__ static inline double mean_std_parts(const uint64_t *s, double N, doub
     return sqrt(var);
 }
 
-__global__ void __launch_bounds__(256)
-finalize_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_empty, int C, int loss,
-                int n_render, double n_pix, LinkFlags lf, double *__restrict__ err)
+// sums -> float64 error of one candidate (the reference's order of operations, predict.py:480-509)
+__device__ static inline double finalize_one(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_empty, int c, int loss,
+                                             int n_render, double n_pix, const LinkFlags &lf)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
     uint64_t s[ROPE_SUM_WORDS];
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) {
@@ -862,34 +864,35 @@ finalize_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_
         sums[(size_t)c * ROPE_SUM_WORDS + k] = s[k];
     }
     double m1, sd = mean_std_parts(s, n_pix, m1);
-    double e;
-    if (loss == ROPE_LOSS_LOOKUP) e = m1 * sd;
-    else if (loss == ROPE_LOSS_TSWEEP) e = m1 * -sd;
-    else {
-        e = 0.0;
-        if (loss == ROPE_LOSS_FULL)
-            for (int l = 1; l < n_render; l++) {
-                if (!(lf.f[l] & 1)) continue;
-                e += ((double)s[SUM_LINK0 + 3 * l] / n_pix) * 5.0;
-                if ((lf.f[l] & 2) && s[SUM_LINK0 + 3 * l + 1] > 0)
-                    e += (((double)s[SUM_LINK0 + 3 * l + 2] * 0x1p-32) / (double)s[SUM_LINK0 + 3 * l + 1]) * 10.0;
-            }
-        double meanD = ((double)s[SUM_S1] * 0x1p-32) / (double)s[SUM_CNT];
-        e += meanD * sd;
-    }
-    err[c] = e;
+    if (loss == ROPE_LOSS_LOOKUP) return m1 * sd;
+    if (loss == ROPE_LOSS_TSWEEP) return m1 * -sd;
+    double e = 0.0;
+    if (loss == ROPE_LOSS_FULL)
+        for (int l = 1; l < n_render; l++) {
+            if (!(lf.f[l] & 1)) continue;
+            e += ((double)s[SUM_LINK0 + 3 * l] / n_pix) * 5.0;
+            if ((lf.f[l] & 2) && s[SUM_LINK0 + 3 * l + 1] > 0)
+                e += (((double)s[SUM_LINK0 + 3 * l + 2] * 0x1p-32) / (double)s[SUM_LINK0 + 3 * l + 1]) * 10.0;
+        }
+    double meanD = ((double)s[SUM_S1] * 0x1p-32) / (double)s[SUM_CNT];
+    e += meanD * sd;
+    return e;
 }
 
-// First index of the smallest error (NaN never wins against a number).  One block.
+// One block: every candidate's error, then the first index of the smallest one by wave shuffles
+// (NaN never wins against a number).  err[C] and err[C+1] receive the best error and its index, so that
+// one device-to-host copy returns everything.
 __global__ void __launch_bounds__(1024)
-argmin_kernel(const double *__restrict__ err, int C, int32_t *__restrict__ best_idx, double *__restrict__ best_err)
+finalize_argmin_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_empty, int C, int loss, int n_render,
+                       double n_pix, LinkFlags lf, double *__restrict__ err)
 {
     __shared__ double s_e[16];
     __shared__ int s_i[16];
     double be = __builtin_inf();
     int bi = 0x7FFFFFFF;
     for (int i = threadIdx.x; i < C; i += blockDim.x) {
-        double e = err[i];
+        const double e = finalize_one(sums, total_empty, i, loss, n_render, n_pix, lf);
+        err[i] = e;
         if (e < be || (e == be && i < bi) || (bi == 0x7FFFFFFF && !(e != e))) { be = e; bi = i; }
     }
 #pragma unroll
@@ -911,7 +914,11 @@ argmin_kernel(const double *__restrict__ err, int C, int32_t *__restrict__ best_
             int oi = __shfl_xor(bi, off, 64);
             if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
         }
-        if (lane == 0) { *best_idx = (bi == 0x7FFFFFFF) ? 0 : bi; *best_err = (bi == 0x7FFFFFFF) ? err[0] : be; }
+        if (lane == 0) {
+            // all-NaN input: index 0 and its (NaN) error, as the first element
+            err[C] = (bi == 0x7FFFFFFF) ? err[0] : be;
+            err[C + 1] = (bi == 0x7FFFFFFF) ? 0.0 : (double)bi;
+        }
     }
 }
 
@@ -934,19 +941,18 @@ static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const R
 }
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
-                     const double *joint_axes, const double *PV, float *mvp)
+                     const double *joint_axes, const double *PV, float *mvp, uint64_t *sums, uint32_t *mask_lo,
+                     uint32_t *mask_hi, int mask_words)
 {
-    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, mvp);
+    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, mvp,
+                       sums, mask_lo, mask_hi, mask_words);
     return hipGetLastError();
 }
 
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words)
 {
-    hipError_t e = hipMemsetAsync(mask_lo, 0, (size_t)C * mask_words * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(mask_hi, 0, (size_t)C * mask_words * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
+    // the masks were cleared by fk_mvp_kernel earlier in the same pass
     hipLaunchKernelGGL(bounds_kernel, dim3((rp.n_meshlets + 255) / 256, C), dim3(256), 0, st, fp, rp, n_render, n_shared, mvp,
                        bounds, mask_lo, mask_hi, mask_words);
     return hipGetLastError();
@@ -987,10 +993,10 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
 }
 
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
-                           double n_pix, const LinkFlags &lf, double *err, int32_t *best_idx, double *best_err)
+                           double n_pix, const LinkFlags &lf, double *err /* C + 2 doubles */)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, total_empty, C, loss, n_render, n_pix, lf, err);
-    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, st, err, C, best_idx, best_err);
+    hipLaunchKernelGGL(finalize_argmin_kernel, dim3(1), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, sums, total_empty, C, loss,
+                       n_render, n_pix, lf, err);
     return hipGetLastError();
 }
 

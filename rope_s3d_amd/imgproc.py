@@ -15,6 +15,21 @@ def resize_linear(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
     H, W = img.shape[:2]
     if (out_w, out_h) == (W, H):
         return img.copy()
+    if W % out_w == 0 and H % out_h == 0 and W // out_w == H // out_h and (W // out_w) % 2 == 0:
+        # even integer factor f: both taps have weight 1/2 and sit at f/2-1, f/2 of every block, so the four
+        # strided views below are exactly the gathers of the general path (same operations, same order)
+        f = W // out_w
+        a, b = f // 2 - 1, f // 2
+        if img.dtype == np.uint8:
+            s = img.astype(np.int64)
+            r0 = (s[a::f, a::f] * 1024 + s[a::f, b::f] * 1024) >> 4
+            r1 = (s[b::f, a::f] * 1024 + s[b::f, b::f] * 1024) >> 4
+            return np.clip((((1024 * r0) >> 16) + ((1024 * r1) >> 16) + 2) >> 2, 0, 255).astype(np.uint8)
+        work = img.astype(np.float64 if img.dtype == np.float64 else np.float32)
+        h = work.dtype.type(0.5)
+        top = work[a::f, a::f] * h + work[a::f, b::f] * h
+        bot = work[b::f, a::f] * h + work[b::f, b::f] * h
+        return (top * h + bot * h).astype(img.dtype)
 
     def taps(n_out, n_in):
         scale = n_in / n_out
