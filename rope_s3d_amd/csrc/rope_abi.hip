@@ -64,6 +64,10 @@ struct rope_ctx {
     int32_t *d_best_idx = nullptr;
     int last_n_render = 0;
 
+    // small batches: per-candidate tiles in global memory that split workgroups merge into
+    uint32_t *d_gtile = nullptr;
+    size_t gtile_cap = 0;
+
     // stored lookup table (cropped sqrt-depth of a pose grid)
     float *d_table = nullptr;
     size_t table_cap = 0;
@@ -136,7 +140,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_table, c->d_zero_total, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_table, c->d_zero_total, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -400,6 +404,27 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     RasterArgs a = base_args(c, n_render);
+    // Few candidates (descent pairs, flips): one workgroup per (tile, candidate) would leave most of the chip idle,
+    // so the meshlets of each tile are split over several workgroups that merge into a tile in global memory.
+    int split = 1;
+    if (!layers && !(fp.debug & 1024)) {
+        split = std::min(16, 768 / std::max(1, c->C * c->n_tiles));
+        if (split < 2) split = 1;
+    }
+    if (split > 1) {
+        const size_t need = (size_t)c->C * c->n_tiles * (TILE_W * TILE_H);
+        if (need > c->gtile_cap) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, realloc_dev(&c->d_gtile, need));
+            c->gtile_cap = need;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_gtile, 0xFF, need * sizeof(uint32_t), c->stream));
+        RasterArgs sa = a;
+        sa.split = split; sa.gtile = c->d_gtile;
+        HIP_TRY(c, launch_raster(MODE_SPLIT, loss, c->C, c->stream, fp, c->rp, sa));
+        a.l_begin = a.l_end = n_render;            // nothing left to rasterise in the scoring launch
+        a.from_gtile = 1; a.gtile = c->d_gtile;
+    }
     if (layers) {
         RasterArgs la = a;
         la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;

@@ -46,7 +46,7 @@ constexpr uint32_t D24_MAX = 16777215u;
 enum { SUM_CNT = 0, SUM_S1 = 1, SUM_AA = 2, SUM_AB = 3, SUM_BB = 4, SUM_LINK0 = 5 };
 static_assert(SUM_LINK0 + 3 * ROPE_MAX_LINKS == ROPE_SUM_WORDS, "sum layout");
 
-enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3, MODE_TABLE = 4 };
+enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3, MODE_TABLE = 4, MODE_SPLIT = 5 };
 
 struct FrameParams {
     int W, H, tiles_x, tiles_y;
@@ -82,6 +82,10 @@ struct RasterArgs {
     const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
     uint64_t *sums; uint32_t *key_out; uint8_t *cover;
     float *table;                         // MODE_TABLE: C x crop_h x crop_w sqrt-depth (crop = fp.r0..c1)
+    // few candidates: the meshlets of a (tile, candidate) are split over `split` workgroups (grid z) that merge
+    // their LDS tiles into gtile with atomicMin (MODE_SPLIT); a MODE_SCORE launch with from_gtile then scores it
+    int split, from_gtile;
+    uint32_t *gtile;                      // C x n_tiles x (TILE_W*TILE_H) keys, cleared to 0xFFFFFFFF
 };
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,

@@ -528,6 +528,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     const uint32_t *layer_tile = nullptr;
     if (MODE != MODE_LAYER && ra.layer_of && hit_lo)
         layer_tile = ra.layers + ((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
+    // MODE_SCORE after a MODE_SPLIT launch: the whole tile was rasterised already and sits in global memory
+    const bool from_gtile = (MODE == MODE_SCORE) && ra.from_gtile;
+    if (from_gtile) layer_tile = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
 
     if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
     if (tid == 0) { s_count = 0; s_next = 0; }
@@ -538,7 +541,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     {
         const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
         const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
+        const int zsplit = (MODE == MODE_SPLIT) ? (int)gridDim.z : 1, zme = (MODE == MODE_SPLIT) ? (int)blockIdx.z : 0;
         for (int m = m_begin + tid; m < m_end; m += NTHREADS) {
+            if (zsplit > 1 && (m % zsplit) != zme) continue;       // this workgroup's share of the meshlets
             const short4 b = bb[m];
             const int bx0 = b.x & 0x3FFF;
             if (bx0 <= b.y && bx0 <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
@@ -549,7 +554,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     }
     __syncthreads();
     const int n_list = s_count;
-    if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile)) {
+    if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile) && !from_gtile) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
         if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
             const uint64_t d = ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
@@ -769,6 +774,13 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         }
         return;
     }
+    if (MODE == MODE_SPLIT) {
+        // merge this workgroup's share into the candidate's tile in global memory (min is order-free)
+        uint32_t *dst = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
+        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS)
+            if (tile[i] != KEY_EMPTY) atomicMin(&dst[i], tile[i]);
+        return;
+    }
     if (MODE == MODE_TABLE) {
         // one row of the lookup table: sqrt of the metric depth over the crop (predict.py:117 sqrt of the table,
         // lookup.py:92 crop); samples nothing was drawn on stay 0 from the table's memset
@@ -796,11 +808,11 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         return;
     }
     if (fp.debug & 16) return;
-    score_tile<LOSS, true>(tile, layer_tile, row0, col0, fp, n_render, tq, t32, lds_sums);
+    score_tile<LOSS, true>(tile, from_gtile ? nullptr : layer_tile, row0, col0, fp, n_render, tq, t32, lds_sums);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
         uint64_t delta = lds_sums[tid];
-        if (layer_tile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
+        if (layer_tile && !from_gtile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
         if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
     }
 }
@@ -961,10 +973,11 @@ hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const Rob
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                          const RasterArgs &a)
 {
-    dim3 grid(fp.tiles_x * fp.tiles_y, rows);
+    dim3 grid(fp.tiles_x * fp.tiles_y, rows, mode == MODE_SPLIT ? a.split : 1);
     if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a);
     else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a);
     else if (mode == MODE_TABLE) launch_one<ROPE_LOSS_LOOKUP, MODE_TABLE>(grid, st, fp, rp, a);
+    else if (mode == MODE_SPLIT) launch_one<ROPE_LOSS_DEPTH, MODE_SPLIT>(grid, st, fp, rp, a);
     else if (mode == MODE_LAYER) {
         if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a);
         else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a);

@@ -110,3 +110,23 @@ def test_stored_lookup_table_scores_equal_on_the_fly(scene):
         assert np.array_equal(scores[::5].view(np.uint64), ref.view(np.uint64))
         scores2, bi3, _ = e.lookup_score(want_scores=True)             # table survives the other launches
         assert np.array_equal(scores2.view(np.uint64), scores.view(np.uint64)) and bi3 == bi
+
+
+def test_small_batch_split_does_not_change_results(scene):
+    """1-6 candidates: meshlets of a tile spread over several workgroups merged by atomicMin == one workgroup per tile."""
+    rb, intr, PV, o, e = scene
+    d, ids = o.render([0.35, 0.45, 0.9, 0, 0, 0])
+    tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+    e.set_target(tq, t32, flags)
+    cand = np.array(POSES + [[0.36, 0.44, 0.91, 0, 0, 0]], np.float64)
+    for n_c in (1, 2, 6):
+        for loss, n in ((eng.LOSS_FULL, 6), (eng.LOSS_FULL, 4), (eng.LOSS_DEPTH, 6)):
+            err_a, sums_a, bi_a, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
+            e.debug_skip(1024)
+            try:
+                err_b, sums_b, bi_b, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
+            finally:
+                e.debug_skip(0)
+            assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
+            ref = o.eval(cand[:n_c], loss, n, tq, t32, None, flags, threads=4)
+            assert np.array_equal(err_a.view(np.uint64), ref.view(np.uint64))
