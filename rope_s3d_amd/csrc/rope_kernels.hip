@@ -830,12 +830,23 @@ table_score_kernel(FrameParams fp, const float *__restrict__ table, const float 
     __syncthreads();
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    auto one = [&](int i, float d) {
         const int r = i / cw, c = i - r * cw;
         const float t = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
-        const uint64_t dq = q32_of_f32(fabsf(t - row[i]));
+        const uint64_t dq = q32_of_f32(fabsf(t - d));
         if (dq) acc_sq<false>(s, dq);
+    };
+    // 16-byte loads where the row start allows it (rows are n floats apart, so alignment depends on the row)
+    const int head = (int)((4 - (((size_t)blockIdx.x * n) & 3)) & 3);
+    for (int i = threadIdx.x; i < head && i < n; i += blockDim.x) one(i, row[i]);
+    const int n4 = (n - head) >> 2;
+    const float4 *row4 = reinterpret_cast<const float4 *>(row + head);
+    for (int i4 = threadIdx.x; i4 < n4; i4 += blockDim.x) {
+        const float4 d = row4[i4];
+        const int i = head + 4 * i4;
+        one(i, d.x); one(i + 1, d.y); one(i + 2, d.z); one(i + 3, d.w);
     }
+    for (int i = head + 4 * n4 + threadIdx.x; i < n; i += blockDim.x) one(i, row[i]);
     const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
