@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--grid', type=int, default=16, help='S/L/U divisions per joint (16 -> 4096 candidates)')
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL over xGMI); 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -87,9 +88,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # ROPE_FORCE_DEVICE: rehearsal of the N>1 control flow on a box with one GPU (all ranks share device 0)
+    device = int(os.environ.get('ROPE_FORCE_DEVICE', local_rank))
+    torch.cuda.set_device(device)
+    coll_dev = torch.device('cuda', device) if args.backend == 'nccl' else torch.device('cpu')
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(args.backend)
 
     from rope_s3d_amd import engine as eng
     from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
@@ -101,7 +108,7 @@ def main():
     W, H = intr.width, intr.height
     PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
 
-    e = eng.Engine(local_rank)
+    e = eng.Engine(device)
     e.set_robot(robot)
     e.set_camera(PV, W, H, ZNEAR, ZFAR)
 
@@ -125,7 +132,7 @@ def main():
         e.eval_resident(6, eng.LOSS_DEPTH)
     e.sync()
 
-    best = torch.zeros(6, dtype=torch.float64, device='cuda')
+    best = torch.zeros(6, dtype=torch.float64, device=coll_dev)
     barrier()
     t0 = time.perf_counter()
     # the K timed steps run inside rope_profile_eval, which brackets every kernel with HIP events
@@ -139,7 +146,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
