@@ -65,7 +65,7 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample):
     o.eval(sample, orc.LOSS_DEPTH, 6, tq, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": len(sample) / dt, "unit": "poses/s", "cores": threads, "kind": "port",
-            "sample": f"first {len(sample)} of the 4096 grid candidates, {threads} threads over candidates, "
+            "sample": f"first {len(sample)} of the {len(cand)} grid candidates, {threads} threads over candidates, "
                       f"{dt:.2f} s wall"}
 
 
@@ -74,7 +74,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--grid', type=int, default=16, help='S/L/U divisions per joint (16 -> 4096 candidates)')
+    ap.add_argument('--grid', type=int, default=None, help='S/L/U divisions per joint (default 16 -> 4096 candidates; cfg5: 32)')
+    ap.add_argument('--workload', default='cfg1', choices=['cfg1', 'cfg5'],
+                    help="cfg1 = BASELINE configs[1] (default, the metric's configuration); cfg5 = configs[4] geometry on one GPU: "
+                         "mh50, 1280x720, 32^3 candidates")
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL over xGMI); 'gloo' only to rehearse N>1 on a one-GPU box")
@@ -103,10 +106,21 @@ def main():
     from rope_s3d_amd.projection import Intrinsics, view_matrix
     from rope_s3d_amd.robot import RobotModel
 
-    robot = RobotModel.from_urdf()
-    intr = Intrinsics('640_480_color')
+    from rope_s3d_amd.urdf import URDFReader
+    if args.workload == 'cfg5':
+        robot = RobotModel.from_urdf(URDFReader(os.path.join(ROOT, 'urdfs/motoman_mh50_support/urdf/mh50.urdf')))
+        intr, cam_pose = Intrinsics('1280_720_color'), [0, -4.0, 1.5, 0, 0, 0]      # camera pulled back for the larger arm
+        b_cand = 12 * 27498 + 12 * 55421 + 2 * 1280 * 720 * 2                     # = 4 681 428 (fp16 depth in the §8d model)
+        label = "configs[4] geometry on one GPU: mh50 URDF, 1280x720, %d candidates/frame (%d^3 SLU grid), depth-only loss, 6 links"
+        args.grid = args.grid or 32
+    else:
+        robot = RobotModel.from_urdf()
+        intr, cam_pose = Intrinsics('640_480_color'), DEFAULT_CAMERA_POSE
+        b_cand = B_CAND
+        label = "configs[1]: mh5l_limited URDF, 640x480, %d candidates/frame (%d^3 SLU grid), depth-only loss, 6 links, one frame per rank"
+        args.grid = args.grid or 16
     W, H = intr.width, intr.height
-    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(cam_pose)
 
     e = eng.Engine(device)
     e.set_robot(robot)
@@ -153,22 +167,21 @@ def main():
     if rank == 0:
         poses = world * args.steps * C
         raster_s = kern['raster'] * 1e-3
-        achieved = B_CAND * C / raster_s / 1e9
+        achieved = b_cand * C / raster_s / 1e9
         out = {
-            "metric": "rendered+scored candidate poses/sec @640x480",
+            "metric": "rendered+scored candidate poses/sec @%dx%d" % (W, H),
             "value": poses / dt, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32/i64 fixed-point edge functions, f32 depth, u64 Q32 sums",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: mh5l_limited URDF, 640x480, 4096 candidates/frame (16^3 SLU grid), "
-                                   "depth-only loss, 6 links, one frame per rank",
+            "config": {"workload": label % (C, args.grid),
                        "candidates_per_step": C, "frames_per_rank": 1, "parallelism": f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "raster_score_kernel<DEPTH,SCORE> (+ its <DEPTH,LAYER> launch: links 0-2 once per distinct (S,L))",
                          "kernel_ms": kern['raster'], "score_launch_ms": kern['score'], "layer_launch_ms": kern['layer'],
-                         "bytes_per_candidate": B_CAND, "candidates_per_launch": C,
+                         "bytes_per_candidate": b_cand, "candidates_per_launch": C,
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
                                               "pass_total": kern['total']}},
         }

@@ -16,8 +16,10 @@ from .constants import NUM_RENDER_LINKS
 from .stl import load_mesh
 from .urdf import URDFReader
 
-MESHLET_MAX_TRIS = 128
-MESHLET_MAX_VERTS = 128
+import os as _os
+
+MESHLET_MAX_TRIS = int(_os.environ.get('ROPE_MESHLET_TRIS', 128))      # engine limit: 128
+MESHLET_MAX_VERTS = int(_os.environ.get('ROPE_MESHLET_VERTS', 128))    # engine limit: 128
 
 
 def _rpy_matrix(rpy) -> np.ndarray:
