@@ -1,15 +1,21 @@
 // rope_kernels.hip — CDNA4 (gfx950) kernels of the render-and-compare pose engine.
 //
-// One pass over a batch of candidate joint vectors is three launches:
-//   fk_mvp_kernel        per candidate: joint angles -> link world transforms -> P·V·M
-//                        (stands in for klampt FK, robotpose/simulation/kinematics.py:36-55,
-//                        and pyrender's node poses, render.py:88-90)
-//   raster_score_kernel  per (candidate, 64x64 screen tile): meshlet culling, vertex shading,
-//                        triangle set-up and z-test into an LDS depth/id tile, then the
-//                        per-pixel loss terms reduced to exact integer sums
-//                        (stands in for pyrender's SEG pass, render.py:92-98, and
-//                        Predictor._error / the lookup reduction, predict.py:475-509,165-171)
-//   finalize_kernel      integer sums -> float64 error, then a wave-shuffle argmin
+// One pass over a batch of candidate joint vectors:
+//   fk_mvp_kernel           per candidate: joint angles -> link world transforms -> P·V·M; clears the
+//                           candidate's accumulators (stands in for klampt FK,
+//                           robotpose/simulation/kinematics.py:36-55, and pyrender's node poses, render.py:88-90)
+//   bounds_kernel           per (meshlet, candidate): screen box + the candidate's masks of touched tiles
+//   raster_score_kernel     per (128x48 screen tile, row): meshlet list, vertex shading, triangle cull and
+//     <LOSS, MODE>          set-up, z-test into an LDS depth/id tile, then the loss terms of the covered samples
+//                           as exact integer sums (stands in for pyrender's SEG pass, render.py:92-98, and
+//                           Predictor._error / the lookup reduction, predict.py:475-509,165-171).  Modes:
+//                             LAYER  links 0-2 once per distinct (q0,q1) -> key tiles + their loss sums in HBM
+//                             SCORE  a candidate's remaining links on top of its layer; loss delta
+//                             SPLIT  few candidates: a tile's meshlets over several workgroups, merged by atomicMin
+//                             TABLE  rows of the stored lookup table (cropped sqrt-depth)
+//                             DUMP / COVER  single-pose render, crop search
+//   finalize_argmin_kernel  integer sums -> float64 errors, wave-shuffle argmin
+//   table_score_kernel      Lookup stage against the stored table: pure streaming
 //
 // Arithmetic contract: all floating point steps are single IEEE-754
 // operations in the written order (built with -ffp-contract=off; fmaf where fused),
@@ -135,10 +141,6 @@ __device__ static inline uint64_t q32_of_f32(float z)
     return sh >= 0 ? (m << sh) : (sh > -64 ? (m >> -sh) : 0);
 }
 
-struct Acc {
-    uint64_t w[ROPE_SUM_WORDS];
-};
-
 // NEG subtracts instead of adds (modulo 2^64): lets "sums(tile) - sums(base)" live in one set of registers
 template <bool NEG>
 __device__ static inline void acc(uint64_t &w, uint64_t x) { if (NEG) w -= x; else w += x; }
@@ -199,7 +201,7 @@ __device__ static inline bool pixel_active(int row, int col, int W, int H, int r
 // Loss sums of one tile.  DELTA = false: plain sums of a tile with nothing rendered.
 // DELTA = true: sums(tile) - sums(base tile), which only the samples whose key differs contribute to —
 // all others are skipped without touching the target planes.  Arithmetic is
-// modulo 2^64, the frame total of the "nothing rendered" sums is added back by finalize_kernel.
+// modulo 2^64, the frame total of the "nothing rendered" sums is added back by finalize_argmin_kernel.
 template <int LOSS, bool DELTA>
 __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *__restrict__ base /* global, or nullptr = nothing */,
                                          int row0, int col0, const FrameParams &fp, int n_render,
