@@ -31,24 +31,35 @@ def _mask(letters):
 
 
 def predict_reference(o: orc.Oracle, tgt_depth, tgt_blue, link_names, link_blue, joint_limits, camera_pose,
-                      lookup_angles, lookup_crop, do_angles='SLU', min_ang_inc=None, stages=None):
-    """-> (final angles, trace [(stage kind, angles after it)], number of E(a) evaluations)."""
+                      lookup_angles, lookup_crop, do_angles='SLU', min_ang_inc=None, stages=None, seg_masks=None,
+                      lookup_depth=None):
+    """-> (final angles, trace [(stage kind, angles after it)], number of E(a) evaluations).
+
+    Synthetic mode (default): masks are read from `tgt_blue` as _loadSynthetic does.  Segmentation mode:
+    pass `seg_masks` {link name: bool mask} and `lookup_depth` as _segmentLoad/_load_target leave them
+    (predict.py:397-442); `tgt_depth` is then the body-masked depth."""
     min_ang_inc = np.array([.005] * 6) if min_ang_inc is None else np.asarray(min_ang_inc, float)
     tgt_depth = np.asarray(tgt_depth, np.float64)
     H, W = tgt_depth.shape
     n_pix = float(H * W)
 
-    # --- _loadSynthetic (predict.py:445-469)
-    new = np.zeros(tgt_depth.shape)
-    for k in link_blue:
-        if k in link_names[:6]:
-            new += tgt_blue == link_blue[k]
-    lookup_depth = tgt_depth * new.astype(bool).astype(float)
+    if seg_masks is None:
+        # --- _loadSynthetic (predict.py:445-469)
+        new = np.zeros(tgt_depth.shape)
+        for k in link_blue:
+            if k in link_names[:6]:
+                new += tgt_blue == link_blue[k]
+        lookup_depth = tgt_depth * new.astype(bool).astype(float)
+        seg_masks = {}
+        for link in link_names:
+            m = tgt_blue == link_blue[link]
+            if np.sum(m.astype(float)) > 0:
+                seg_masks[link] = m
     bits = np.zeros(tgt_depth.shape, np.uint64)
     flags = np.zeros(8, np.uint8)
     for l, link in enumerate(link_names):
-        m = tgt_blue == link_blue[link]
-        if np.sum(m.astype(float)) > 0:
+        if link in seg_masks:                              # _load_target (predict.py:408-413)
+            m = np.asarray(seg_masks[link], bool)
             bits |= m.astype(np.uint64) << np.uint64(l)
             flags[l] |= 1
             if np.sum((m * tgt_depth) != 0) > (.05 * np.sum(m)):

@@ -55,6 +55,23 @@ def _not_a_knot(x, y, xq):
         + (y[i + 1] / h[i] - M[i + 1] * h[i] / 6) * t0
 
 
+def segment_targets(seg: dict, target_depth: np.ndarray, lookup_links) -> np.ndarray:
+    """Depth masking of the segmentation path (predict.py:419-438).
+
+    Zeroes `target_depth` IN PLACE outside erode7(dilate8(sum of all link masks)) and returns the lookup
+    depth: a copy further restricted to the links the lookup table renders."""
+    def body(keys):
+        new = np.zeros(target_depth.shape)
+        for k in keys:
+            new += seg[k]['mask']
+        return erode(dilate(new, 8), 7).astype(bool).astype(float)
+
+    target_depth *= body(seg.keys())
+    lookup_depth = target_depth.copy()
+    lookup_depth *= body([k for k in seg if k in lookup_links])
+    return lookup_depth
+
+
 class Predictor:
 
     def __init__(self,
@@ -189,16 +206,7 @@ class Predictor:
                 "stage on PyTorch-ROCm is SURVEY §8f rank 1), or color_dict for synthetic input")
         r = self.seg(self._downsample(target_color, self.ds_factor))
         seg = self._reorganize_by_link(r)
-
-        def body(keys):
-            new = np.zeros(target_depth.shape)
-            for k in keys:
-                new += seg[k]['mask']
-            return erode(dilate(new, 8), 7).astype(bool).astype(float)      # predict.py:419-428
-
-        target_depth *= body(seg.keys())
-        lookup_depth = target_depth.copy()
-        lookup_depth *= body([k for k in seg if k in self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED]])
+        lookup_depth = segment_targets(seg, target_depth, self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED])
         self._upload_target(target_depth, lookup_depth, {k: v['mask'] for k, v in seg.items()})
         return target_depth
 

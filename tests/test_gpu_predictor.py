@@ -63,3 +63,35 @@ def test_predictor_trace_matches_sequential_reference(synth, seed):
     assert np.array_equal(got, want)
     # the synthetic pose is recovered to within the descent's terminal resolution
     assert np.abs(got - q_true)[:3].max() < 0.25     # 4^3 lookup grid: coarse start, sanity bound only
+
+
+def test_segmentation_path_trace_matches_reference(synth):
+    """Non-synthetic mode: a segmenter supplies instance masks (two per link here), Predictor._segmentLoad merges
+    them, masks the depth with the dilate-8/erode-7 body and the stage machine runs on that target."""
+    from rope_s3d_amd import Predictor
+    from rope_s3d_amd.prediction.predict import segment_targets
+    from rope_s3d_amd.segmentation import ColorSegmenter
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    names = ['BG'] + rb.link_names
+    seg_fn = ColorSegmenter(names, split_instances=True)
+    p = Predictor(DEFAULT_CAMERA_POSE, 4, base_intrin='640_480_color', segmenter=seg_fn, lookup_divisions=4)
+    q_true = np.random.default_rng(123).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    synth.renderer.setJointAngles(q_true)
+    color, depth = synth.renderer.render()
+    depth_in = depth.astype(np.float64)
+    got = p.run(color, depth_in)
+
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    o = helpers.make_oracle(rb, intr, PV)
+    small = resize_linear(color, intr.width, intr.height)
+    seg = Predictor._reorganize_by_link(p, seg_fn(small))
+    tgt = resize_linear(depth.astype(np.float64), intr.width, intr.height)
+    lookup = segment_targets(seg, tgt, rb.link_names)
+    want, trace, _ = predictor_ref.predict_reference(
+        o, tgt, None, rb.link_names, {}, lim, DEFAULT_CAMERA_POSE, helpers.slu_grid(lim, 4), p.lookup_crop, 'SLU',
+        seg_masks={k: v['mask'] for k, v in seg.items()}, lookup_depth=lookup)
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
+    assert np.abs(got - q_true)[:3].max() < 0.25

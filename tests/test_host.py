@@ -222,3 +222,33 @@ def test_engine_refuses_to_run_without_gpu():
     from rope_s3d_amd import Renderer
     with pytest.raises(engine.EngineUnavailable):
         Renderer('seg', [0, -1.5, .75, 0, 0, 0], '640_480_color')
+
+
+def test_segmentation_path_target_preparation():
+    """_reorganize_by_link + the dilate-8 / erode-7 body mask (predict.py:383-395,419-438) against a literal write-out."""
+    from rope_s3d_amd.prediction.predict import Predictor, segment_targets
+    from rope_s3d_amd.segmentation import ColorSegmenter
+    names = ['BG', 'base_link', 'link_1_s', 'link_2_l', 'link_3_u', 'link_4_r', 'link_5_b']
+    H, W = 40, 60
+    color = np.zeros((H, W, 3), np.uint8)
+    cols = constants.DEFAULT_RENDER_COLORS
+    color[25:38, 10:30] = cols[0]; color[12:25, 15:28] = cols[1]; color[5:12, 18:40] = cols[2]; color[6:9, 44:50] = cols[4]
+    depth = np.random.default_rng(0).uniform(1.0, 2.0, (H, W))
+    r = ColorSegmenter(names, split_instances=True)(color)
+    assert len(r['class_ids']) == 8 and r['masks'].shape == (H, W, 8)          # two instances per visible link
+    fake = type('P', (), {'classes': names})()
+    seg = Predictor._reorganize_by_link(fake, r)
+    assert set(seg) == {'base_link', 'link_1_s', 'link_2_l', 'link_4_r'}
+    assert np.array_equal(seg['link_2_l']['mask'], (color[..., 0] == cols[2][0]) & (color[..., 2] == cols[2][2]))
+    assert seg['link_2_l']['confidence'] == 1.0
+    d = depth.copy()
+    lookup = segment_targets(seg, d, names[1:7])
+    # literal restatement of predict.py:419-438 with the window operations written as loops
+    def box(img, k, fn, pad):
+        a = k // 2
+        p = np.full((H + k - 1, W + k - 1), pad); p[a:a + H, a:a + W] = img
+        return np.array([[fn(p[y:y + k, x:x + k]) for x in range(W)] for y in range(H)])
+    new = sum(seg[k]['mask'].astype(float) for k in seg)
+    body = box(box(new, 8, np.max, -np.inf), 7, np.min, np.inf).astype(bool).astype(float)
+    assert np.array_equal(d, depth * body) and np.array_equal(lookup, depth * body * body)
+    assert (d[body == 0] == 0).all() and d[30, 20] == depth[30, 20]
