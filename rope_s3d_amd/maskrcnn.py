@@ -1,0 +1,268 @@
+"""Mask R-CNN inference on PyTorch-ROCm — the segmentation stage in front of the HIP engine.
+
+The reference segments the RGB frame with PixelLib 0.5.6 `custom_segmentation` (Matterport's Keras
+Mask R-CNN, ResNet-101 + FPN; robotpose/prediction/predict.py:94-98,416; trained in train.py:49).
+This module restates that network's INFERENCE graph in plain torch (torchvision is not in the image):
+ResNet-101 C1..C5, FPN P2..P6, RPN over 5 scales x 3 ratios, proposal layer (top 6000, NMS 0.7,
+1000 kept), pyramid RoIAlign (7x7 head, 14x14 mask), two-layer classifier head, detection layer
+(score >= 0.7, per-class NMS 0.3, 100 instances), mask head (4 convs + deconv, 28x28 sigmoid), and the
+un-moulding of masks into the image.  PixelLib's inference config for this call: 512x512 square input,
+detection threshold 0.7 (pixellib custom_segmentation.inferConfig defaults).
+
+No trained weights exist offline (models/*.h5 are git-ignored upstream and h5py is absent), so the
+network is random-initialised: it exercises the dense-contraction path (MIOpen convolutions on the
+matrix cores, bf16 autocast, channels-last) and the adapter into `Predictor._segmentLoad`, but its masks
+are not comparable with the reference's.  `load_state_dict` takes converted weights when they exist.
+The dense work is the only part of the prediction path where MFMA is the right tool; everything after
+it (FK, raster, loss) is the hand-written HIP engine.
+"""
+import math
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+MEAN_PIXEL = (123.7, 116.8, 103.9)               # Matterport Config.MEAN_PIXEL (RGB)
+BACKBONE_STRIDES = (4, 8, 16, 32, 64)
+RPN_ANCHOR_SCALES = (32, 64, 128, 256, 512)
+RPN_ANCHOR_RATIOS = (0.5, 1.0, 2.0)
+RPN_BBOX_STD_DEV = (0.1, 0.1, 0.2, 0.2)
+BBOX_STD_DEV = (0.1, 0.1, 0.2, 0.2)
+PRE_NMS_LIMIT, POST_NMS_ROIS, RPN_NMS_THRESHOLD = 6000, 1000, 0.7
+DETECTION_MAX_INSTANCES, DETECTION_NMS_THRESHOLD = 100, 0.3
+POOL_SIZE, MASK_POOL_SIZE, MASK_SHAPE = 7, 14, 28
+TOP_DOWN_PYRAMID_SIZE, FPN_CLASSIF_FC = 256, 1024
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=1e-3)             # Keras BatchNormalization default epsilon; frozen at inference
+
+
+class _Bottleneck(nn.Module):
+    """Matterport identity_block / conv_block: 1x1 -> 3x3 -> 1x1 with a projection shortcut when the shape changes."""
+
+    def __init__(self, cin, mid, stride, project):
+        super().__init__()
+        self.c1, self.b1 = nn.Conv2d(cin, mid, 1, stride), _bn(mid)
+        self.c2, self.b2 = nn.Conv2d(mid, mid, 3, 1, 1), _bn(mid)
+        self.c3, self.b3 = nn.Conv2d(mid, mid * 4, 1), _bn(mid * 4)
+        self.short = nn.Sequential(nn.Conv2d(cin, mid * 4, 1, stride), _bn(mid * 4)) if project else None
+
+    def forward(self, x):
+        y = F.relu(self.b1(self.c1(x)))
+        y = F.relu(self.b2(self.c2(y)))
+        y = self.b3(self.c3(y))
+        return F.relu(y + (x if self.short is None else self.short(x)))
+
+
+class _ResNet(nn.Module):
+    def __init__(self, blocks=(3, 4, 23, 3)):       # resnet101
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3), _bn(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
+        stages, cin = [], 64
+        for i, (n, mid) in enumerate(zip(blocks, (64, 128, 256, 512))):
+            layers = [_Bottleneck(cin, mid, 1 if i == 0 else 2, True)]
+            layers += [_Bottleneck(mid * 4, mid, 1, False) for _ in range(n - 1)]
+            stages.append(nn.Sequential(*layers))
+            cin = mid * 4
+        self.stages = nn.ModuleList(stages)
+
+    def forward(self, x):
+        x = self.stem(x)
+        out = []
+        for s in self.stages:
+            x = s(x)
+            out.append(x)
+        return out                                   # C2, C3, C4, C5
+
+
+class _FPN(nn.Module):
+    def __init__(self, c=TOP_DOWN_PYRAMID_SIZE):
+        super().__init__()
+        self.lat = nn.ModuleList([nn.Conv2d(k, c, 1) for k in (256, 512, 1024, 2048)])
+        self.smooth = nn.ModuleList([nn.Conv2d(c, c, 3, 1, 1) for _ in range(4)])
+
+    def forward(self, feats):
+        c2, c3, c4, c5 = feats
+        p5 = self.lat[3](c5)
+        p4 = self.lat[2](c4) + F.interpolate(p5, scale_factor=2, mode='nearest')
+        p3 = self.lat[1](c3) + F.interpolate(p4, scale_factor=2, mode='nearest')
+        p2 = self.lat[0](c2) + F.interpolate(p3, scale_factor=2, mode='nearest')
+        p2, p3, p4, p5 = [s(p) for s, p in zip(self.smooth, (p2, p3, p4, p5))]
+        return [p2, p3, p4, p5, F.max_pool2d(p5, 1, 2)]          # P6 for the RPN only
+
+
+class _RPN(nn.Module):
+    def __init__(self, c=TOP_DOWN_PYRAMID_SIZE, a=len(RPN_ANCHOR_RATIOS)):
+        super().__init__()
+        self.shared = nn.Conv2d(c, 512, 3, 1, 1)
+        self.cls, self.box = nn.Conv2d(512, 2 * a, 1), nn.Conv2d(512, 4 * a, 1)
+
+    def forward(self, p):
+        h = F.relu(self.shared(p))
+        logits = self.cls(h).permute(0, 2, 3, 1).reshape(p.shape[0], -1, 2)
+        deltas = self.box(h).permute(0, 2, 3, 1).reshape(p.shape[0], -1, 4)
+        return logits.float().softmax(-1)[..., 1], deltas.float()
+
+
+def _pyramid_anchors(size: int, device) -> torch.Tensor:
+    """Matterport utils.generate_pyramid_anchors (anchor stride 1), normalised to [0,1] as norm_boxes does."""
+    out = []
+    for scale, stride in zip(RPN_ANCHOR_SCALES, BACKBONE_STRIDES):
+        n = int(math.ceil(size / stride))
+        ratios = torch.tensor(RPN_ANCHOR_RATIOS, device=device)
+        hs, ws = scale / ratios.sqrt(), scale * ratios.sqrt()
+        ys = torch.arange(n, device=device, dtype=torch.float32) * stride
+        cy, cx = torch.meshgrid(ys, ys, indexing='ij')
+        cy, cx = cy[..., None].expand(n, n, 3), cx[..., None].expand(n, n, 3)
+        b = torch.stack([cy - 0.5 * hs, cx - 0.5 * ws, cy + 0.5 * hs, cx + 0.5 * ws], -1).reshape(-1, 4)
+        out.append(b)
+    a = torch.cat(out)
+    scale = torch.tensor([size - 1, size - 1, size - 1, size - 1], device=device, dtype=torch.float32)
+    shift = torch.tensor([0, 0, 1, 1], device=device, dtype=torch.float32)
+    return (a - shift) / scale
+
+
+def _apply_deltas(boxes, deltas):
+    h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cy, cx = boxes[:, 0] + 0.5 * h + deltas[:, 0] * h, boxes[:, 1] + 0.5 * w + deltas[:, 1] * w
+    h, w = h * deltas[:, 2].exp(), w * deltas[:, 3].exp()
+    return torch.stack([cy - 0.5 * h, cx - 0.5 * w, cy + 0.5 * h, cx + 0.5 * w], 1)
+
+
+def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int) -> torch.Tensor:
+    """Greedy non-maximum suppression (tf.image.non_max_suppression): indices kept, best first.
+    The pairwise IoU matrix is one GPU op; the inherently serial sweep runs over it on the host."""
+    if boxes.numel() == 0:
+        return torch.zeros(0, dtype=torch.long, device=boxes.device)
+    order = scores.argsort(descending=True)
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
+    tl, br = torch.max(b[:, None, :2], b[None, :, :2]), torch.min(b[:, None, 2:], b[None, :, 2:])
+    inter = (br - tl).clamp(min=0).prod(-1)
+    iou = (inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-12)).cpu().numpy()
+    alive = np.ones(len(b), bool)
+    keep = []
+    for i in range(len(b)):
+        if alive[i]:
+            keep.append(i)
+            if len(keep) >= limit:
+                break
+            alive &= ~(iou[i] > thr)
+    return order[torch.as_tensor(keep, dtype=torch.long, device=boxes.device)]
+
+
+def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: int) -> torch.Tensor:
+    """PyramidROIAlign: level by box area, then tf.image.crop_and_resize (bilinear, pool x pool samples spanning the box)."""
+    h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    lvl = (4 + torch.log2((h * w).clamp(min=1e-12).sqrt() / (224.0 / size)).round()).clamp(2, 5).long()
+    out = boxes.new_zeros((len(boxes), feats[0].shape[1], pool, pool), dtype=feats[0].dtype)
+    t = torch.linspace(0, 1, pool, device=boxes.device)
+    for k in range(2, 6):
+        idx = (lvl == k).nonzero().squeeze(1)
+        if idx.numel() == 0:
+            continue
+        f = feats[k - 2]
+        b = boxes[idx]
+        ys = b[:, 0:1] + t[None, :] * (b[:, 2:3] - b[:, 0:1])         # normalised [0,1] sample rows
+        xs = b[:, 1:2] + t[None, :] * (b[:, 3:4] - b[:, 1:2])
+        grid = torch.stack([(xs * 2 - 1)[:, None, :].expand(-1, pool, -1), (ys * 2 - 1)[:, :, None].expand(-1, -1, pool)], -1)
+        out[idx] = F.grid_sample(f.expand(len(idx), -1, -1, -1), grid.to(f.dtype), mode='bilinear', padding_mode='zeros', align_corners=True)
+    return out
+
+
+class MaskRCNN(nn.Module):
+
+    def __init__(self, num_classes: int = 7, image_size: int = 512, min_confidence: float = 0.7):
+        super().__init__()
+        self.num_classes, self.size, self.min_conf = num_classes, image_size, min_confidence
+        self.backbone, self.fpn, self.rpn = _ResNet(), _FPN(), _RPN()
+        c = TOP_DOWN_PYRAMID_SIZE
+        self.head = nn.Sequential(nn.Conv2d(c, FPN_CLASSIF_FC, POOL_SIZE), _bn(FPN_CLASSIF_FC), nn.ReLU(),
+                                  nn.Conv2d(FPN_CLASSIF_FC, FPN_CLASSIF_FC, 1), _bn(FPN_CLASSIF_FC), nn.ReLU())
+        self.cls, self.box = nn.Linear(FPN_CLASSIF_FC, num_classes), nn.Linear(FPN_CLASSIF_FC, num_classes * 4)
+        mask = []
+        for _ in range(4):
+            mask += [nn.Conv2d(c, c, 3, 1, 1), _bn(c), nn.ReLU()]
+        self.mask = nn.Sequential(*mask, nn.ConvTranspose2d(c, c, 2, 2), nn.ReLU(), nn.Conv2d(c, num_classes, 1))
+
+    @torch.no_grad()
+    def detect(self, image_rgb: torch.Tensor):
+        """image_rgb (H,W,3) uint8 on the module's device -> (class_ids (K,), scores (K,), masks (H,W,K) bool)."""
+        dev = image_rgb.device
+        H, W = image_rgb.shape[:2]
+        scale = self.size / max(H, W)                                   # resize_image(mode='square')
+        nh, nw = round(H * scale), round(W * scale)
+        top, left = (self.size - nh) // 2, (self.size - nw) // 2
+        x = image_rgb.permute(2, 0, 1)[None].float()
+        x = F.interpolate(x, (nh, nw), mode='bilinear', align_corners=False)
+        x = x - torch.tensor(MEAN_PIXEL, device=dev).view(1, 3, 1, 1)
+        x = F.pad(x, (left, self.size - nw - left, top, self.size - nh - top))
+        window = torch.tensor([top, left, top + nh, left + nw], device=dev, dtype=torch.float32)
+        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=dev.type == 'cuda'):
+            feats = self.fpn(self.backbone(x.contiguous(memory_format=torch.channels_last)))
+            probs, deltas = zip(*[self.rpn(p) for p in feats])
+        probs, deltas = torch.cat(probs, 1)[0], torch.cat(deltas, 1)[0]
+        anchors = _pyramid_anchors(self.size, dev)
+        k = min(PRE_NMS_LIMIT, len(probs))
+        top_idx = probs.topk(k).indices
+        boxes = _apply_deltas(anchors[top_idx], deltas[top_idx] * torch.tensor(RPN_BBOX_STD_DEV, device=dev)).clamp(0, 1)
+        rois = boxes[_nms(boxes, probs[top_idx], RPN_NMS_THRESHOLD, POST_NMS_ROIS)]
+        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=dev.type == 'cuda'):
+            h = self.head(_roi_align(feats, rois, POOL_SIZE, self.size)).flatten(1)
+            cls_prob = self.cls(h).float().softmax(-1)
+            box_delta = self.box(h).float().view(-1, self.num_classes, 4)
+        cls_id = cls_prob.argmax(1)
+        score = cls_prob.gather(1, cls_id[:, None])[:, 0]
+        d = box_delta[torch.arange(len(rois), device=dev), cls_id] * torch.tensor(BBOX_STD_DEV, device=dev)
+        nwin = (window - torch.tensor([0, 0, 1, 1], device=dev)) / (self.size - 1)
+        refined = _apply_deltas(rois, d)
+        refined = torch.stack([refined[:, 0].clamp(nwin[0], nwin[2]), refined[:, 1].clamp(nwin[1], nwin[3]),
+                               refined[:, 2].clamp(nwin[0], nwin[2]), refined[:, 3].clamp(nwin[1], nwin[3])], 1)
+        keep = ((cls_id > 0) & (score >= self.min_conf)).nonzero().squeeze(1)
+        final = []
+        for c in cls_id[keep].unique():                                  # per-class NMS (refine_detections_graph)
+            ix = keep[cls_id[keep] == c]
+            final.append(ix[_nms(refined[ix], score[ix], DETECTION_NMS_THRESHOLD, DETECTION_MAX_INSTANCES)])
+        if not final:
+            return (torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros((H, W, 0), dtype=torch.bool))
+        keep = torch.cat(final)
+        keep = keep[score[keep].argsort(descending=True)[:DETECTION_MAX_INSTANCES]]
+        det_boxes, det_cls, det_score = refined[keep], cls_id[keep], score[keep]
+        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=dev.type == 'cuda'):
+            m = self.mask(_roi_align(feats, det_boxes, MASK_POOL_SIZE, self.size)).float().sigmoid()
+        m = m[torch.arange(len(keep), device=dev), det_cls]              # (K, 28, 28) of each detection's class
+        # un-mould: boxes back to original image pixels, masks resized into their box (utils.unmold_mask)
+        px = det_boxes * (self.size - 1) + torch.tensor([0, 0, 1, 1], device=dev)
+        px = ((px - torch.tensor([top, left, top, left], device=dev)) / scale).round().long()
+        masks = torch.zeros((H, W, len(keep)), dtype=torch.bool, device=dev)
+        for i in range(len(keep)):
+            y1, x1, y2, x2 = [int(v) for v in px[i]]
+            y1, x1, y2, x2 = max(y1, 0), max(x1, 0), min(y2, H), min(x2, W)
+            if y2 <= y1 or x2 <= x1:
+                continue
+            mm = F.interpolate(m[i][None, None], (y2 - y1, x2 - x1), mode='bilinear', align_corners=False)[0, 0]
+            masks[y1:y2, x1:x2, i] = mm >= 0.5
+        return det_cls.cpu(), det_score.cpu(), masks.cpu()
+
+
+class MaskRCNNSegmenter:
+    """`segmenter=` adapter: colour frame (H,W,3 uint8, BGR as the dataset stores it) -> PixelLib-style result dict."""
+
+    def __init__(self, num_classes: int = 7, device: str = 'cuda:0', state_dict: dict = None, seed: int = 0,
+                 min_confidence: float = 0.7):
+        torch.manual_seed(seed)
+        self.device = torch.device(device)
+        self.net = MaskRCNN(num_classes, min_confidence=min_confidence)
+        if state_dict is not None:
+            self.net.load_state_dict(state_dict)
+        self.net = self.net.to(self.device).eval()
+        if self.device.type == 'cuda':
+            self.net = self.net.to(memory_format=torch.channels_last)
+
+    def __call__(self, color_bgr: np.ndarray) -> dict:
+        rgb = torch.from_numpy(np.ascontiguousarray(color_bgr[..., ::-1])).to(self.device)
+        cls, score, masks = self.net.detect(rgb)
+        return {'class_ids': cls.numpy(), 'scores': score.numpy(), 'masks': masks.numpy()}

@@ -1,0 +1,55 @@
+"""Segmentation stage (plain-torch Mask R-CNN, random weights): structure on CPU, execution + adapter on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from rope_s3d_amd.maskrcnn import MaskRCNN, MaskRCNNSegmenter, _nms, _pyramid_anchors, _roi_align
+
+
+def test_anchor_pyramid_and_parameter_count():
+    a = _pyramid_anchors(512, 'cpu')
+    assert a.shape == ((128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2 + 8 ** 2) * 3, 4)
+    # first anchor of the stride-4 level: centre (0,0), scale 32, ratio 0.5 -> h = 32/sqrt(.5), w = 32*sqrt(.5), normalised by 511
+    h, w = 32 / np.sqrt(0.5), 32 * np.sqrt(0.5)
+    assert np.allclose(a[0].numpy(), [(-h / 2) / 511, (-w / 2) / 511, (h / 2 - 1) / 511, (w / 2 - 1) / 511], atol=1e-6)
+    net = MaskRCNN(7)
+    n = sum(p.numel() for p in net.parameters())
+    assert 63.0e6 < n < 64.5e6                 # ResNet-101 + FPN Mask R-CNN with 7 classes
+    assert len(net.backbone.stages[2]) == 23   # resnet101's third stage
+
+
+def test_greedy_nms_and_roi_align():
+    b = torch.tensor([[0, 0, 1, 1], [0, 0, .9, .9], [.5, .5, 1, 1], [0, 0, .5, .5]], dtype=torch.float32)
+    s = torch.tensor([.9, .8, .7, .6])
+    assert _nms(b, s, 0.5, 10).tolist() == [0, 2, 3] and _nms(b, s, 0.5, 2).tolist() == [0, 2]
+    feats = [torch.linspace(0, 1, n).view(1, 1, 1, n).expand(1, 1, n, n).contiguous() for n in (128, 64, 32, 16)]
+    out = _roi_align(feats, torch.tensor([[0.0, 0.25, 1.0, 0.75]]), 7, 512)
+    assert np.allclose(out[0, 0, 0].numpy(), np.linspace(0.25, 0.75, 7), atol=1e-6)   # samples span the box, corners included
+
+
+def test_cpu_forward_is_well_formed_and_deterministic():
+    img = np.random.default_rng(0).integers(0, 255, (60, 80, 3), dtype=np.uint8)
+    a = MaskRCNNSegmenter(7, device='cpu', seed=3, min_confidence=0.0)(img)
+    b = MaskRCNNSegmenter(7, device='cpu', seed=3, min_confidence=0.0)(img)
+    k = len(a['class_ids'])
+    assert 0 < k <= 100 and a['masks'].shape == (60, 80, k) and a['masks'].dtype == bool
+    assert (a['class_ids'] > 0).all() and (a['class_ids'] < 7).all() and (np.diff(a['scores']) <= 1e-6).all()
+    assert np.array_equal(a['class_ids'], b['class_ids']) and np.array_equal(a['masks'], b['masks'])
+
+
+@pytest.mark.gpu
+def test_gpu_forward_and_predictor_adapter():
+    from rope_s3d_amd import Predictor, Renderer
+    from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
+    seg = MaskRCNNSegmenter(7, device='cuda:0', seed=1, min_confidence=0.0)
+    r = Renderer('seg', DEFAULT_CAMERA_POSE, '640_480_color')
+    r.setJointAngles([0.3, 0.4, 0.9, 0, 0, 0])
+    color, depth = r.render()
+    out = seg(color)
+    k = len(out['class_ids'])
+    assert 0 < k <= 100 and out['masks'].shape == (480, 640, k)
+    # whole pipeline on the segmentation path: untrained masks are meaningless, the plumbing must still hold
+    p = Predictor(DEFAULT_CAMERA_POSE, 4, base_intrin='640_480_color', segmenter=seg, lookup_divisions=4)
+    angles = p.run(color, depth.astype(np.float64))
+    assert angles.shape == (6,) and np.isfinite(angles).all()
+    assert (angles[:3] >= r.robot.joint_limits[:3, 0] - 1e-9).all() and (angles[:3] <= r.robot.joint_limits[:3, 1] + 1e-9).all()
