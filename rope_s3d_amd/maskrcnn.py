@@ -11,7 +11,7 @@ detection threshold 0.7 (pixellib custom_segmentation.inferConfig defaults).
 
 No trained weights exist offline (models/*.h5 are git-ignored upstream and h5py is absent), so the
 network is random-initialised: it exercises the dense-contraction path (MIOpen convolutions on the
-matrix cores, bf16 autocast, channels-last) and the adapter into `Predictor._segmentLoad`, but its masks
+matrix cores: bf16 weights, channels-last, batch norms folded) and the adapter into `Predictor._segmentLoad`, but its masks
 are not comparable with the reference's.  `load_state_dict` takes converted weights when they exist.
 The dense work is the only part of the prediction path where MFMA is the right tool; everything after
 it (FK, raster, loss) is the hand-written HIP engine.
@@ -142,7 +142,7 @@ def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int) -> t
     area = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
     tl, br = torch.max(b[:, None, :2], b[None, :, :2]), torch.min(b[:, None, 2:], b[None, :, 2:])
     inter = (br - tl).clamp(min=0).prod(-1)
-    iou = (inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-12)).cpu().numpy()
+    sup = ((inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-12)) > thr).cpu().numpy()   # 1 byte per pair
     alive = np.ones(len(b), bool)
     keep = []
     for i in range(len(b)):
@@ -150,27 +150,66 @@ def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int) -> t
             keep.append(i)
             if len(keep) >= limit:
                 break
-            alive &= ~(iou[i] > thr)
+            alive &= ~sup[i]
     return order[torch.as_tensor(keep, dtype=torch.long, device=boxes.device)]
 
 
 def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: int) -> torch.Tensor:
-    """PyramidROIAlign: level by box area, then tf.image.crop_and_resize (bilinear, pool x pool samples spanning the box)."""
+    """PyramidROIAlign: level by box area, then tf.image.crop_and_resize (bilinear, pool x pool samples spanning
+    the box, corners included).  Four gathers per level straight from the (C,H,W) map: no per-ROI feature copies."""
     h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
     lvl = (4 + torch.log2((h * w).clamp(min=1e-12).sqrt() / (224.0 / size)).round()).clamp(2, 5).long()
-    out = boxes.new_zeros((len(boxes), feats[0].shape[1], pool, pool), dtype=feats[0].dtype)
+    C = feats[0].shape[1]
+    out = boxes.new_zeros((len(boxes), C, pool, pool), dtype=feats[0].dtype)
     t = torch.linspace(0, 1, pool, device=boxes.device)
     for k in range(2, 6):
         idx = (lvl == k).nonzero().squeeze(1)
         if idx.numel() == 0:
             continue
-        f = feats[k - 2]
-        b = boxes[idx]
-        ys = b[:, 0:1] + t[None, :] * (b[:, 2:3] - b[:, 0:1])         # normalised [0,1] sample rows
-        xs = b[:, 1:2] + t[None, :] * (b[:, 3:4] - b[:, 1:2])
-        grid = torch.stack([(xs * 2 - 1)[:, None, :].expand(-1, pool, -1), (ys * 2 - 1)[:, :, None].expand(-1, -1, pool)], -1)
-        out[idx] = F.grid_sample(f.expand(len(idx), -1, -1, -1), grid.to(f.dtype), mode='bilinear', padding_mode='zeros', align_corners=True)
+        f = feats[k - 2][0]                                          # (C, Hf, Wf)
+        Hf, Wf = f.shape[1], f.shape[2]
+        b = boxes[idx].float()
+        ys = (b[:, 0:1] + t[None, :] * (b[:, 2:3] - b[:, 0:1])) * (Hf - 1)     # (K, P) in feature pixels
+        xs = (b[:, 1:2] + t[None, :] * (b[:, 3:4] - b[:, 1:2])) * (Wf - 1)
+        y0, x0 = ys.floor(), xs.floor()
+        wy, wx = (ys - y0).to(f.dtype), (xs - x0).to(f.dtype)
+        inside_y = ((ys >= 0) & (ys <= Hf - 1)).to(f.dtype)          # crop_and_resize extrapolates with 0 outside the map
+        inside_x = ((xs >= 0) & (xs <= Wf - 1)).to(f.dtype)
+        y0c, y1c = y0.long().clamp(0, Hf - 1), (y0.long() + 1).clamp(0, Hf - 1)
+        x0c, x1c = x0.long().clamp(0, Wf - 1), (x0.long() + 1).clamp(0, Wf - 1)
+
+        def g(yi, xi):                                               # -> (C, K, P, P)
+            return f[:, yi[:, :, None].expand(-1, -1, pool), xi[:, None, :].expand(-1, pool, -1)]
+        wy_, wx_ = wy[None, :, :, None], wx[None, :, None, :]
+        val = (g(y0c, x0c) * (1 - wy_) + g(y1c, x0c) * wy_) * (1 - wx_) + (g(y0c, x1c) * (1 - wy_) + g(y1c, x1c) * wy_) * wx_
+        val = val * inside_y[None, :, :, None] * inside_x[None, :, None, :]
+        out[idx] = val.permute(1, 0, 2, 3)
     return out
+
+
+def _fold_batchnorm(module: nn.Module) -> nn.Module:
+    """Inference only: fold every frozen BatchNorm2d into the convolution in front of it (fewer launches, same function)."""
+    def fold(conv, bn):
+        w = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        conv.weight.data = conv.weight.data * w.view(-1, 1, 1, 1)
+        bias = conv.bias.data if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        conv.bias = nn.Parameter((bias - bn.running_mean) * w + bn.bias.data)
+
+    for m in module.modules():
+        if isinstance(m, _Bottleneck):
+            for c, b in (('c1', 'b1'), ('c2', 'b2'), ('c3', 'b3')):
+                fold(getattr(m, c), getattr(m, b))
+                setattr(m, b, nn.Identity())
+            if m.short is not None:
+                fold(m.short[0], m.short[1])
+                m.short[1] = nn.Identity()
+        elif isinstance(m, nn.Sequential):
+            kids = list(m.children())
+            for i in range(len(kids) - 1):
+                if isinstance(kids[i], nn.Conv2d) and isinstance(kids[i + 1], nn.BatchNorm2d):
+                    fold(kids[i], kids[i + 1])
+                    m[i + 1] = nn.Identity()
+    return module
 
 
 class MaskRCNN(nn.Module):
@@ -201,19 +240,18 @@ class MaskRCNN(nn.Module):
         x = x - torch.tensor(MEAN_PIXEL, device=dev).view(1, 3, 1, 1)
         x = F.pad(x, (left, self.size - nw - left, top, self.size - nh - top))
         window = torch.tensor([top, left, top + nh, left + nw], device=dev, dtype=torch.float32)
-        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=dev.type == 'cuda'):
-            feats = self.fpn(self.backbone(x.contiguous(memory_format=torch.channels_last)))
-            probs, deltas = zip(*[self.rpn(p) for p in feats])
+        wdt = next(self.parameters()).dtype                              # bf16 on the GPU (cast once), f32 on CPU
+        feats = self.fpn(self.backbone(x.to(wdt).contiguous(memory_format=torch.channels_last)))
+        probs, deltas = zip(*[self.rpn(p) for p in feats])
         probs, deltas = torch.cat(probs, 1)[0], torch.cat(deltas, 1)[0]
         anchors = _pyramid_anchors(self.size, dev)
         k = min(PRE_NMS_LIMIT, len(probs))
         top_idx = probs.topk(k).indices
         boxes = _apply_deltas(anchors[top_idx], deltas[top_idx] * torch.tensor(RPN_BBOX_STD_DEV, device=dev)).clamp(0, 1)
         rois = boxes[_nms(boxes, probs[top_idx], RPN_NMS_THRESHOLD, POST_NMS_ROIS)]
-        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=dev.type == 'cuda'):
-            h = self.head(_roi_align(feats, rois, POOL_SIZE, self.size)).flatten(1)
-            cls_prob = self.cls(h).float().softmax(-1)
-            box_delta = self.box(h).float().view(-1, self.num_classes, 4)
+        h = self.head(_roi_align(feats, rois, POOL_SIZE, self.size)).flatten(1)
+        cls_prob = self.cls(h).float().softmax(-1)
+        box_delta = self.box(h).float().view(-1, self.num_classes, 4)
         cls_id = cls_prob.argmax(1)
         score = cls_prob.gather(1, cls_id[:, None])[:, 0]
         d = box_delta[torch.arange(len(rois), device=dev), cls_id] * torch.tensor(BBOX_STD_DEV, device=dev)
@@ -231,8 +269,7 @@ class MaskRCNN(nn.Module):
         keep = torch.cat(final)
         keep = keep[score[keep].argsort(descending=True)[:DETECTION_MAX_INSTANCES]]
         det_boxes, det_cls, det_score = refined[keep], cls_id[keep], score[keep]
-        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=dev.type == 'cuda'):
-            m = self.mask(_roi_align(feats, det_boxes, MASK_POOL_SIZE, self.size)).float().sigmoid()
+        m = self.mask(_roi_align(feats, det_boxes, MASK_POOL_SIZE, self.size)).float().sigmoid()
         m = m[torch.arange(len(keep), device=dev), det_cls]              # (K, 28, 28) of each detection's class
         # un-mould: boxes back to original image pixels, masks resized into their box (utils.unmold_mask)
         px = det_boxes * (self.size - 1) + torch.tensor([0, 0, 1, 1], device=dev)
@@ -258,9 +295,9 @@ class MaskRCNNSegmenter:
         self.net = MaskRCNN(num_classes, min_confidence=min_confidence)
         if state_dict is not None:
             self.net.load_state_dict(state_dict)
-        self.net = self.net.to(self.device).eval()
-        if self.device.type == 'cuda':
-            self.net = self.net.to(memory_format=torch.channels_last)
+        self.net = _fold_batchnorm(self.net.eval()).to(self.device)
+        if self.device.type == 'cuda':                                   # weights to bf16 once: MFMA path of MIOpen / hipBLASLt
+            self.net = self.net.to(torch.bfloat16).to(memory_format=torch.channels_last)
 
     def __call__(self, color_bgr: np.ndarray) -> dict:
         rgb = torch.from_numpy(np.ascontiguousarray(color_bgr[..., ::-1])).to(self.device)
