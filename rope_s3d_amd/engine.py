@@ -174,11 +174,25 @@ class Engine:
         self._check(self._lib.rope_results_download(self._ctx, _p(err), _p(sums), C.byref(bi), C.byref(be)), 'rope_results_download')
         return err, sums, int(bi.value), float(be.value)
 
+    MAX_BATCH = 65535          # candidates per launch (grid y dimension)
+
     def eval(self, cand, n_render: int, loss: int, crop=None, want_sums=False):
-        """-> (err (C,), sums or None, first-argmin index, its error)."""
-        self.upload_candidates(cand)
-        self.eval_resident(n_render, loss, crop)
-        return self.download(True, want_sums)
+        """-> (err (C,), sums or None, first-argmin index, its error).  Any number of candidates: batches beyond
+        65 535 rows are evaluated in several launches and merged (first index of the smallest error, NaN never wins)."""
+        cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
+        if len(cand) <= self.MAX_BATCH:
+            self.upload_candidates(cand)
+            self.eval_resident(n_render, loss, crop)
+            return self.download(True, want_sums)
+        errs, sums, best, best_err = [], [], -1, np.nan
+        for lo in range(0, len(cand), self.MAX_BATCH):
+            e, s, bi, be = self.eval(cand[lo:lo + self.MAX_BATCH], n_render, loss, crop, want_sums)
+            errs.append(e)
+            sums.append(s)
+            if best < 0 or be < best_err or (np.isnan(best_err) and not np.isnan(be)):
+                best, best_err = lo + bi, be
+        self.n_candidates = min(len(cand) - (len(cand) - 1) // self.MAX_BATCH * self.MAX_BATCH, self.MAX_BATCH)
+        return np.concatenate(errs), (np.concatenate(sums) if want_sums else None), best, best_err
 
     def lookup_build(self, cand, n_render: int, crop):
         """Render the pose grid once into an HBM-resident table of cropped sqrt-depth images."""

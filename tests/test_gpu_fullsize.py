@@ -162,3 +162,17 @@ def test_abi_rejects_bad_calls():
         e.set_target(np.zeros((3, 3), np.uint64))
     e.eval_resident(6, eng.LOSS_DEPTH)                              # still usable after the refused calls
     e.sync()
+
+
+def test_more_candidates_than_one_launch_holds():
+    """70 000 rows (> 65 535 per launch) at a small resolution: chunked evaluation, merged argmin."""
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '640_480_color', ds=8)
+    d, ids = e.render([0.3, 0.4, 0.9, 0, 0, 0], 6)
+    e.set_target(eng.pack_target(d.astype(np.float64)), None, np.zeros(8, np.uint8))
+    base = helpers.slu_grid(rb.joint_limits, 10)                      # 1000 distinct poses
+    cand = np.tile(base, (70, 1))                                      # 70 000 rows
+    err, _, bi, be = e.eval(cand, 6, eng.LOSS_DEPTH)
+    ref, _, bi0, be0 = e.eval(base, 6, eng.LOSS_DEPTH)
+    assert err.shape == (70000,) and np.array_equal(err.reshape(70, 1000).view(np.uint64), np.tile(ref.view(np.uint64), (70, 1)))
+    assert bi == bi0 and be == be0                                     # first occurrence wins across launches too
