@@ -907,17 +907,26 @@ __device__ static inline double finalize_one(uint64_t *__restrict__ sums, const 
 // One block: every candidate's error, then the first index of the smallest one by wave shuffles
 // (NaN never wins against a number).  err[C] and err[C+1] receive the best error and its index, so that
 // one device-to-host copy returns everything.
+// large batches: the errors come from a grid of blocks, the single argmin block then only reduces them
+__global__ void __launch_bounds__(256)
+finalize_only_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_empty, int C, int loss, int n_render,
+                     double n_pix, LinkFlags lf, double *__restrict__ err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) err[i] = finalize_one(sums, total_empty, i, loss, n_render, n_pix, lf);
+}
+
 __global__ void __launch_bounds__(1024)
 finalize_argmin_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ total_empty, int C, int loss, int n_render,
-                       double n_pix, LinkFlags lf, double *__restrict__ err)
+                       double n_pix, LinkFlags lf, double *__restrict__ err, int have_err)
 {
     __shared__ double s_e[16];
     __shared__ int s_i[16];
     double be = __builtin_inf();
     int bi = 0x7FFFFFFF;
     for (int i = threadIdx.x; i < C; i += blockDim.x) {
-        const double e = finalize_one(sums, total_empty, i, loss, n_render, n_pix, lf);
-        err[i] = e;
+        const double e = have_err ? err[i] : finalize_one(sums, total_empty, i, loss, n_render, n_pix, lf);
+        if (!have_err) err[i] = e;
         if (e < be || (e == be && i < bi) || (bi == 0x7FFFFFFF && !(e != e))) { be = e; bi = i; }
     }
 #pragma unroll
@@ -1021,8 +1030,10 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err /* C + 2 doubles */)
 {
+    const int big = C > 2048;
+    if (big) hipLaunchKernelGGL(finalize_only_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, total_empty, C, loss, n_render, n_pix, lf, err);
     hipLaunchKernelGGL(finalize_argmin_kernel, dim3(1), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, sums, total_empty, C, loss,
-                       n_render, n_pix, lf, err);
+                       n_render, n_pix, lf, err, big);
     return hipGetLastError();
 }
 
