@@ -577,74 +577,21 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     int *const woff = s_qoff[wave];
     unsigned long long *const wmask = s_qmask[wave];
     uint32_t *const wkeep = s_keep[wave];
-    for (;;) {
-        int li = 0;
-        if (lane == 0) li = atomicAdd(&s_next, 1);
-        li = __builtin_amdgcn_readfirstlane(li);
-        if (li >= n_list) break;
-        const int m_entry = __builtin_amdgcn_readfirstlane((int)s_list[li]);
-        const int m = m_entry & 0x7FFF;
-        const bool compact = (m_entry & 0x8000) != 0;     // wave-uniform: chooses the 32-bit set-up
-        const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
-        const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
-        const uint32_t l = h1.w;
-        if (fp.debug & 2) continue;
+    // ---- pass 2 (set-up, classify, rasterise) of one batch of up to 64 surviving triangles held in registers
+    int pend_n = 0;                                   // wave-uniform: lanes [0, pend_n) hold a pending survivor
+    bool pend_compact = true;                         // wave-uniform: all of them come from compact meshlets
+    SVert pa = {0, 0, 0.0f}, pb = pa, pc = pa;
+    uint32_t plink = 0;
+    auto pass2 = [&](const int n_active, const bool compact) {
         {
-            // the link matrix is the same for the whole wave: keep it in scalar registers
-            float mm[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                mm[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_mvp[16 * l + k])));
-#pragma unroll 1
-            for (int v = lane; v < nv; v += 64) {
-                const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
-                wv[v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (fp.debug & 4) continue;
-        // ---- pass 1: cull.  Keep front-facing triangles whose bounding box holds a sample of this tile and
-        // compact them, so that the expensive set-up below runs on full lanes (about one triangle in four survives).
-        int ns = 0;
-        for (int tb = 0; tb < nt; tb += 64) {
-            const int t = tb + lane;
-            bool keep = false;
-            uint32_t packed = 0;
-            if (t < nt) {
-                packed = rp.ml_tris[t0 + t];
-                const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
-                if (a.X != SV_BAD && b.X != SV_BAD && c.X != SV_BAD) {
-                    bool front;
-                    if (compact) front = __mul24(b.X - a.X, c.Y - a.Y) - __mul24(c.X - a.X, b.Y - a.Y) > 0;
-                    else front = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y) > 0;
-                    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
-                    const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
-                    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
-                    const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
-                    keep = front && x0 <= x1 && y0 <= y1;
-                }
-            }
-            const unsigned long long km = __ballot(keep);
-            if (keep) wkeep[ns + __popcll(km & ((1ull << lane) - 1))] = packed;
-            ns += __popcll(km);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (fp.debug & 8) continue;
-        // ---- pass 2: set-up, classify, rasterise
-        for (int tb = 0; tb < ns; tb += 64) {
             int rows = 0;                          // > 0: queued for the row-parallel pass
             // what a queued triangle's owner lane keeps for the lanes that will take its rows
             Edge q0 = {0, 0, 0}, q1 = {0, 0, 0}, q2 = {0, 0, 0};
             Plane qpl = {0.0f, 0.0f, 0.0f};
             int q_ulo = 0, q_uhi = -1, q_v0 = 0, q_dxa = 0, q_dya = 0;
-            const int t = tb + lane;
-            if (t < ns) {
-                const uint32_t packed = wkeep[t];
-                const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
+            if (lane < n_active) {
+                const SVert a = pa, b = pb, c = pc;
+                const uint32_t l = plink;
                 {
                     const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
                     const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
@@ -710,7 +657,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             // order, so a scan of `rows` over the lanes gives every queued triangle its first item; the
             // owner of an item is found from a per-chunk bit mask of "a triangle starts at this item".
             const unsigned long long qmask = __ballot(rows > 0);
-            if (qmask == 0 || (fp.debug & 64)) continue;
+            if (qmask == 0 || (fp.debug & 64)) return;
             int incl = rows;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -749,19 +696,96 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 pl.gx = __shfl(qpl.gx, src, 64); pl.gy = __shfl(qpl.gy, src, 64); pl.dc = __shfl(qpl.dc, src, 64);
                 int ulo = __shfl(q_ulo, src, 64), uhi = __shfl(q_uhi, src, 64);
                 const int v0q = __shfl(q_v0, src, 64), dxa = __shfl(q_dxa, src, 64), dya = __shfl(q_dya, src, 64);
+                const uint32_t lq = (uint32_t)__shfl((int)plink, src, 64);
                 if (item < total) {
                     const int v = v0q + (item - (so & 0xFFFF));
                     clip_span(e0, v, ulo, uhi);
                     clip_span(e1, v, ulo, uhi);
                     clip_span(e2, v, ulo, uhi);
                     const float dy = (float)(v + dya);
-                    for (int u = ulo; u <= uhi; u++) depth_test_write(tile, u, v, pl, (float)(u + dxa), dy, l);
+                    for (int u = ulo; u <= uhi; u++) depth_test_write(tile, u, v, pl, (float)(u + dxa), dy, lq);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    for (;;) {
+        int li = 0;
+        if (lane == 0) li = atomicAdd(&s_next, 1);
+        li = __builtin_amdgcn_readfirstlane(li);
+        if (li >= n_list) break;
+        const int m_entry = __builtin_amdgcn_readfirstlane((int)s_list[li]);
+        const int m = m_entry & 0x7FFF;
+        const bool compact = (m_entry & 0x8000) != 0;     // wave-uniform: chooses the 32-bit set-up
+        const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
+        const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
+        const uint32_t l = h1.w;
+        if (fp.debug & 2) continue;
+        {
+            // the link matrix is the same for the whole wave: keep it in scalar registers
+            float mm[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                mm[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_mvp[16 * l + k])));
+#pragma unroll 1
+            for (int v = lane; v < nv; v += 64) {
+                const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
+                wv[v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fp.debug & 4) continue;
+        // ---- pass 1: cull.  Keep front-facing triangles whose bounding box holds a sample of this tile and
+        // compact them, so that the expensive set-up below runs on full lanes (about one triangle in four survives).
+        int ns = 0;
+        for (int tb = 0; tb < nt; tb += 64) {
+            const int t = tb + lane;
+            bool keep = false;
+            uint32_t packed = 0;
+            if (t < nt) {
+                packed = rp.ml_tris[t0 + t];
+                const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
+                if (a.X != SV_BAD && b.X != SV_BAD && c.X != SV_BAD) {
+                    bool front;
+                    if (compact) front = __mul24(b.X - a.X, c.Y - a.Y) - __mul24(c.X - a.X, b.Y - a.Y) > 0;
+                    else front = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y) > 0;
+                    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
+                    const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
+                    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
+                    const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
+                    keep = front && x0 <= x1 && y0 <= y1;
+                }
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) wkeep[ns + __popcll(km & ((1ull << lane) - 1))] = packed;
+            ns += __popcll(km);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fp.debug & 8) continue;
+        // ---- hand the survivors to free lanes of the pending batch; pass 2 runs whenever 64 are waiting, so that the
+        // expensive set-up and the pixel work execute on full waves (survivors of several meshlets share a batch)
+        for (int taken = 0; taken < ns;) {
+            const int take = min(64 - pend_n, ns - taken);
+            if (lane >= pend_n && lane < pend_n + take) {
+                const uint32_t packed = wkeep[taken + lane - pend_n];
+                pa = wv[packed & 0xFF]; pb = wv[(packed >> 8) & 0xFF]; pc = wv[(packed >> 16) & 0xFF];
+                plink = l;
+            }
+            pend_n += take;
+            taken += take;
+            pend_compact = pend_compact && compact;
+            if (pend_n == 64) {
+                pass2(64, pend_compact);
+                pend_n = 0;
+                pend_compact = true;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (pend_n > 0) pass2(pend_n, pend_compact);
     __syncthreads();
 
     if (MODE == MODE_LAYER) {
