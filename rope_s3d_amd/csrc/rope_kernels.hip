@@ -534,12 +534,28 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     const bool from_gtile = (MODE == MODE_SCORE) && ra.from_gtile;
     if (from_gtile) layer_tile = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
 
-    if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
+    // A candidate whose own links cannot touch this tile (mask_hi comes from the very boxes the list below is built
+    // from) keeps its layer's sums: no list, no tile, no barrier.
+    if (MODE == MODE_SCORE && layer_tile && !from_gtile && !hit_hi) {
+        if (tid < ROPE_SUM_WORDS) {
+            const uint64_t d = ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
+            if (d) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)d);
+        }
+        return;
+    }
     if (tid == 0) { s_count = 0; s_next = 0; }
     if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
     __syncthreads();
 
-    // --- meshlets whose screen box meets this tile
+    // --- tile initialisation (a copy of the layer tile, or "empty"), link matrices, and the list of meshlets whose
+    // screen box meets this tile: all in one phase so that the global loads overlap
+    if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
+    if (layer_tile) {
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
+            reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(layer_tile)[i];
+    } else {
+        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
+    }
     {
         const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
         const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
@@ -564,13 +580,6 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         }
         return;
     }
-    if (layer_tile) {
-        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
-            reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(layer_tile)[i];
-    } else {
-        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
-    }
-    __syncthreads();
 
     // --- one meshlet per wave at a time
     SVert *const wv = s_vert[wave];
