@@ -19,22 +19,26 @@ from rope_s3d_amd.parallel import dist_env, gather_rows, shard_range
 
 def run(args):
     rank, world, local_rank = dist_env()
+    # ROPE_FORCE_DEVICE / ROPE_DIST_BACKEND: rehearse the N>1 flow on a one-GPU box (all ranks on device 0, gloo)
+    gpu = int(os.environ.get('ROPE_FORCE_DEVICE', local_rank))
     device = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        use_gpu = torch.cuda.is_available()
-        if use_gpu:
-            torch.cuda.set_device(local_rank)
-            device = torch.device('cuda', local_rank)
-        dist.init_process_group('nccl' if use_gpu else 'gloo', device_id=device)
+        backend = os.environ.get('ROPE_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            torch.cuda.set_device(gpu)
+            device = torch.device('cuda', gpu)
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     ds = Dataset(args.dataset)
     kwargs = {}
     if ds.attrs.get('synthetic'):
         kwargs['color_dict'] = ds.attrs['color_dict']         # link masks are read from the colour render
     am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
-                   do_angles=args.angs, model_ds=args.dataset, device=local_rank, **kwargs)
+                   do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
 
     lo, hi = shard_range(ds.length, rank, world)
     out = np.zeros((hi - lo, 6))

@@ -115,3 +115,29 @@ def test_predict_dataset_cli_end_to_end(tmp_path, monkeypatch):
     assert err.max() < 0.3 and err.mean() < 0.08          # coarse default grid at 160x120; sanity only
     # frame 0 is the golden frame (seed 7919), but with the default lookup size rule instead of 4^3: same ballpark
     assert np.abs(full[0] - np.asarray(ds.angles)[0])[:3].max() < 0.1
+
+
+def test_predict_dataset_two_ranks_shard_and_gather(tmp_path):
+    """Two processes (gloo, both on GPU 0) predict halves of a 4-frame dataset; the gathered array equals a 1-rank run."""
+    import socket
+    import subprocess
+    import sys
+    from rope_s3d_amd.data.dataset import make_synthetic_dataset
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+    d = make_synthetic_dataset(str(tmp_path / 'synth4r'), 4, base_intrin='640_480_color', seed=8000)
+    env = dict(os.environ, PYTHONPATH=root, ROPE_FORCE_DEVICE='0', ROPE_DIST_BACKEND='gloo', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, os.path.join(root, 'predict_dataset.py'), d, '-ds_factor', '4'],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    single = np.load(tmp_path / 'predictions_synth4r.npy')
+    os.remove(tmp_path / 'predictions_synth4r.npy')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(root, 'predict_dataset.py'), d, '-ds_factor', '4'],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stdout + two.stderr
+    assert np.array_equal(np.load(tmp_path / 'predictions_synth4r.npy'), single)      # frames are independent: same bits
