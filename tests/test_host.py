@@ -252,3 +252,17 @@ def test_segmentation_path_target_preparation():
     body = box(box(new, 8, np.max, -np.inf), 7, np.min, np.inf).astype(bool).astype(float)
     assert np.array_equal(d, depth * body) and np.array_equal(lookup, depth * body * body)
     assert (d[body == 0] == 0).all() and d[30, 20] == depth[30, 20]
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: a missing librope_hip.so is an error at load time, with the build hint in the message."""
+    from rope_s3d_amd import engine
+    with pytest.raises(engine.EngineUnavailable, match='no CPU fallback'):
+        engine.load_library(str(tmp_path / 'librope_hip.so'))
+    import ast
+    import pathlib
+    # nothing in the product package imports the oracle
+    for f in pathlib.Path(engine.__file__).parent.rglob('*.py'):
+        for node in ast.walk(ast.parse(f.read_text())):
+            names = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ''] if isinstance(node, ast.ImportFrom) else [])
+            assert not any(n == 'oracle' or n.startswith('oracle.') for n in names), f

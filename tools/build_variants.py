@@ -4,8 +4,11 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd import build
 VARIANTS = {
-    'full4': '',
-    'full6': '-DROPE_MIN_WAVES_FULL=6',
+    'c4r4': '',
+    'c8r4': '-DROPE_SMALL_TRI_COLS=8',
+    'c8r8': '-DROPE_SMALL_TRI_COLS=8 -DROPE_SMALL_TRI_ROWS=8',
+    'c4r8': '-DROPE_SMALL_TRI_ROWS=8',
+    'c2r2': '-DROPE_SMALL_TRI_COLS=2 -DROPE_SMALL_TRI_ROWS=2',
 }
 for name, flags in VARIANTS.items():
     os.environ['ROPE_HIPCC_EXTRA'] = flags
