@@ -62,9 +62,10 @@ class Meshlets:
     link_first: np.ndarray
 
 
-def _grow_partition(V: np.ndarray, F: np.ndarray, max_t: int, max_v: int):
+def _grow_partition(V: np.ndarray, F: np.ndarray, hard_t: int, hard_v: int, soft_margin: int = 4, absorb_below: int = 24):
     """Region growing over the triangle adjacency graph: compact patches (about half the radius of Morton runs)."""
     import heapq
+    max_t, max_v = hard_t, max(hard_v - soft_margin, 3)
     T = len(F)
     cent = V[F].astype(np.float64).mean(1)
     e = np.sort(np.concatenate([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]]), axis=1)
@@ -114,8 +115,30 @@ def _grow_partition(V: np.ndarray, F: np.ndarray, max_t: int, max_v: int):
                     heapq.heappush(heap, (float(dd @ dd), n))
         carry = [(d, t) for d, t in heap if not visited[t]]
         heapq.heapify(carry)
-        clusters.append(np.array(tris))
-    return clusters
+        clusters.append(tris)
+    # Growth stops a little short of the vertex limit (soft cap) and strands small islands between finished
+    # patches; fold every island into the neighbouring patch it shares most vertices with, up to the hard caps.
+    owner = np.empty(T, np.int64)
+    for ci, tris in enumerate(clusters):
+        owner[tris] = ci
+    vsets = [set(F[tris].ravel().tolist()) for tris in clusters]
+    alive = [True] * len(clusters)
+    for ci in sorted(range(len(clusters)), key=lambda i: len(clusters[i])):
+        if len(clusters[ci]) >= absorb_below:
+            break
+        best, best_shared = -1, 0
+        for cj in {int(owner[n]) for t in clusters[ci] for n in nbr[t]} - {ci}:
+            if not alive[cj] or len(clusters[cj]) + len(clusters[ci]) > hard_t:
+                continue
+            shared = len(vsets[ci] & vsets[cj])
+            if len(vsets[ci]) + len(vsets[cj]) - shared <= hard_v and shared > best_shared:
+                best, best_shared = cj, shared
+        if best >= 0:
+            clusters[best] = clusters[best] + clusters[ci]
+            vsets[best] |= vsets[ci]
+            owner[clusters[ci]] = best
+            alive[ci] = False
+    return [np.array(c) for c, a in zip(clusters, alive) if a]
 
 
 def build_meshlets(link_verts: List[np.ndarray], link_faces: List[np.ndarray]) -> Meshlets:
