@@ -32,7 +32,8 @@ enum {
     ROPE_LOSS_DEPTH = 0,  /* last term of Predictor._error only: mean(D[D!=0])*std(D)   predict.py:503-507 */
     ROPE_LOSS_FULL = 1,   /* whole Predictor._error                                      predict.py:475-509 */
     ROPE_LOSS_LOOKUP = 2, /* Lookup stage score mean|T-sqrt(D)|*std over the crop        predict.py:165-171 */
-    ROPE_LOSS_TSWEEP = 3  /* TensorSweep score  mean|sqrt(T)-sqrt(D)| * -std, full frame predict.py:363-369 */
+    ROPE_LOSS_TSWEEP = 3, /* TensorSweep score  mean|sqrt(T)-sqrt(D)| * -std, full frame predict.py:363-369 */
+    ROPE_LOSS_CAMFULL = 4 /* CameraPredictor._error sums (rope_eval_views only)  camera_pose_prediction.py:933-970 */
 };
 
 #define ROPE_MAX_LINKS 6          /* link_6_t is never rendered: render_utils.py:31-32 */
@@ -106,6 +107,22 @@ int rope_render(rope_ctx *ctx, const double *q, int n_render, float *depth, uint
 /* OR over candidates of "pixel covered" (H x W uint8 0/1).  Replaces the depth-sum loop
  * of Crop._create (crop.py:60-81). */
 int rope_coverage(rope_ctx *ctx, const double *cand, int C, int n_render, uint8_t *cover);
+
+/* Camera-pose path: N frames (a known joint vector + target planes each) scored under K candidate cameras.
+ * Replaces do_renders_at_pose + _error of ModellessCameraPredictor / CameraPredictor
+ * (camera_pose_prediction.py:116-124,389-427,656-664,933-970): K x N renders and reductions in one batch.
+ *   q            N x 6 joint vectors (robot_poses)
+ *   tq           N planes H x W uint64, bits 0..38 target depth in Q32 metres
+ *   t32          N planes H x W float32 target depth (ROPE_LOSS_TSWEEP: |sqrt(T)-sqrt(D)|), or NULL
+ *   link_planes  N x 6 planes H x W uint64 (ROPE_LOSS_CAMFULL): bit 40 = link mask, bits 0..38 = mask * depth in
+ *                Q32 metres (_masked_targets / _target_masks, camera_pose_prediction.py:919-931), or NULL
+ * rope_eval_views: PV = K matrices P·V (row-major doubles); sums_out = K x N x ROPE_SUM_WORDS exact integer sums,
+ * candidate order view-major.  Words: ROPE_LOSS_DEPTH / ROPE_LOSS_TSWEEP as rope_results_download;
+ * ROPE_LOSS_CAMFULL: [0] #(D!=0), [1] sum |T-D| (Q32), [2] sum floor(sqrt|T-D| * 2^32), per link l at 5+3l:
+ * #(M_l != R_l), #(d_l != 0), sum floor(sqrt(d_l) * 2^32).  The float epilogue stays with the caller. */
+int rope_set_frames(rope_ctx *ctx, int n_frames, const double *q, const uint64_t *tq, const float *t32,
+                    const uint64_t *link_planes);
+int rope_eval_views(rope_ctx *ctx, const double *PV, int K, int n_render, int loss, uint64_t *sums_out);
 
 /* Device-side per-candidate link matrices of the last eval (C x n_render x 16 float32), for tests. */
 int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);

@@ -6,9 +6,11 @@ Importing the package does not touch the GPU; constructing a Renderer/Predictor 
 from .config import Paths
 from .data.dataset import Dataset
 from .prediction.analysis import Grapher
+from .prediction.camera_pose_prediction import CameraPredictor, ModellessCameraPredictor
 from .prediction.predict import Predictor
 from .prediction.synthetic import SyntheticPredictor
 from .projection import Intrinsics
 from .simulation.render import Renderer
 
-__all__ = ['Paths', 'Dataset', 'Grapher', 'Predictor', 'SyntheticPredictor', 'Intrinsics', 'Renderer']
+__all__ = ['Paths', 'Dataset', 'Grapher', 'Predictor', 'SyntheticPredictor', 'Intrinsics', 'Renderer',
+           'CameraPredictor', 'ModellessCameraPredictor']

@@ -74,6 +74,17 @@ struct rope_ctx {
     int table_C = 0, table_crop[4] = {0, 0, 0, 0};
     uint64_t *d_zero_total = nullptr;
 
+    // camera-pose path: frames (joint vector + target planes each) scored under candidate views
+    int n_frames = 0;
+    bool frames_t32 = false, frames_tl = false;
+    std::vector<double> h_fq;               // n_frames x 6
+    uint64_t *d_ftq = nullptr, *d_ftl = nullptr, *d_ftotal = nullptr, *d_fempty = nullptr;
+    float *d_ft32 = nullptr;
+    double *d_PVs = nullptr;
+    int32_t *d_view_of = nullptr, *d_frame_of = nullptr;
+    int views_cap = 0, vf_cap = 0;
+    int ftotal_loss = -1;                   // loss the per-frame "nothing rendered" totals in d_ftotal belong to
+
     // single-pose render scratch
     uint32_t *d_key = nullptr;
     float *d_depth = nullptr;
@@ -141,7 +152,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
                     c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_table, c->d_zero_total, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
-                    c->d_depth, c->d_ids, c->d_cover, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
+                    c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_PVs, c->d_view_of, c->d_frame_of, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -254,6 +265,7 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
             c->empty_version[k] = 0;
         }
         c->have_target = false;
+        c->n_frames = 0;
     }
     c->have_camera = true;
     return ROPE_OK;
@@ -296,9 +308,16 @@ static int ensure_capacity(rope_ctx *c, int C)
     return ROPE_OK;
 }
 
+static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group);
+
 extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
 {
     if (!c) return ROPE_E_ARG;
+    return upload_candidates(c, cand, C, true);
+}
+
+static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
+{
     if (!cand || C < 1 || C > 65535) ARG_FAIL(c, "rope_candidates_upload: need 1 <= C <= 65535");
     for (size_t i = 0; i < 6 * (size_t)C; i++)
         if (!std::isfinite(cand[i]) || std::fabs(cand[i]) > 1.0e4) ARG_FAIL(c, "rope_candidates_upload: joint angle not finite or |q| > 1e4 rad");
@@ -311,7 +330,7 @@ extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
     // group candidates whose first two joint angles are bit-identical: their base_link, link_1_s and
     // link_2_l transforms are the same bits, so those links are rasterised once per group (a "layer")
     c->n_layers = C;                               // "no sharing" unless the grouping below finds some
-    if (C >= 8) {
+    if (group && C >= 8) {
         struct Key { uint64_t a, b; int idx; };
         std::vector<Key> keys((size_t)C);
         for (int i = 0; i < C; i++) {
@@ -364,7 +383,7 @@ static int ensure_empty(rope_ctx *c, int loss, const FrameParams &fp)
 {
     const int cr[4] = {fp.r0, fp.r1, fp.c0, fp.c1};
     if (c->empty_version[loss] == c->target_version && std::memcmp(cr, c->empty_crop[loss], sizeof cr) == 0) return ROPE_OK;
-    HIP_TRY(c, launch_empty(loss, c->stream, fp, c->d_tq, c->d_t32, c->d_empty[loss], c->d_total[loss]));
+    HIP_TRY(c, launch_empty(loss, c->stream, fp, c->d_tq, c->d_t32, nullptr, c->d_empty[loss], c->d_total[loss]));
     c->empty_version[loss] = c->target_version;
     std::memcpy(c->empty_crop[loss], cr, sizeof cr);
     return ROPE_OK;
@@ -394,13 +413,14 @@ static RasterArgs base_args(rope_ctx *c, int n_render)
 }
 
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
-                        hipEvent_t *ev /* 5 events or nullptr */)
+                        hipEvent_t *ev /* 5 events or nullptr */, bool views = false)
 {
-    const bool layers = want_layers(c) && !(fp.debug & 128);
+    const bool layers = !views && want_layers(c) && !(fp.debug & 128);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, views ? c->d_PVs : c->d_PV,
+                         views ? c->d_view_of : nullptr, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     RasterArgs a = base_args(c, n_render);
@@ -432,10 +452,12 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
-    a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss]; a.sums = c->d_sums;
+    a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss & 3]; a.sums = c->d_sums;
+    if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->d_frame_of; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+    if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
     HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err));
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     c->last_n_render = n_render;
@@ -493,7 +515,7 @@ static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "render: n_render out of range");
     int rc = rope_candidates_upload(c, cand, C);
     if (rc) return rc;
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, nullptr, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, c->fp, c->rp, n_render, 0, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     RasterArgs a = base_args(c, n_render);
     a.key_out = c->d_key; a.cover = c->d_cover;
@@ -561,7 +583,7 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
     const bool layers = want_layers(c);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { rc = ensure_layers(c); if (rc) return rc; }
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, nullptr, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     RasterArgs a = base_args(c, n_render);
     if (layers) {
@@ -596,6 +618,99 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (best_score) *best_score = c->h_stage[0];
     if (best_idx) *best_idx = (int32_t)c->h_stage[1];
+    return ROPE_OK;
+}
+
+extern "C" int rope_set_frames(rope_ctx *c, int n_frames, const double *q, const uint64_t *tq, const float *t32,
+                               const uint64_t *link_planes)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!c->have_camera) ARG_FAIL(c, "rope_set_frames: call rope_set_camera first (image size)");
+    if (!q || !tq || n_frames < 1 || n_frames > 4096) ARG_FAIL(c, "rope_set_frames: need 1 <= n_frames <= 4096, q and tq");
+    for (size_t i = 0; i < 6 * (size_t)n_frames; i++)
+        if (!std::isfinite(q[i]) || std::fabs(q[i]) > 1.0e4) ARG_FAIL(c, "rope_set_frames: joint angle not finite or |q| > 1e4 rad");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t plane = (size_t)c->fp.W * c->fp.H, n = plane * (size_t)n_frames;
+    HIP_TRY(c, realloc_dev(&c->d_ftq, n));
+    HIP_TRY(c, hipMemcpy(c->d_ftq, tq, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    c->frames_t32 = (t32 != nullptr);
+    if (t32) {
+        HIP_TRY(c, realloc_dev(&c->d_ft32, n));
+        HIP_TRY(c, hipMemcpy(c->d_ft32, t32, n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->frames_tl = (link_planes != nullptr);
+    if (link_planes) {
+        HIP_TRY(c, realloc_dev(&c->d_ftl, n * ROPE_MAX_LINKS));
+        HIP_TRY(c, hipMemcpy(c->d_ftl, link_planes, n * ROPE_MAX_LINKS * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, realloc_dev(&c->d_ftotal, (size_t)n_frames * ROPE_SUM_WORDS));
+    HIP_TRY(c, realloc_dev(&c->d_fempty, (size_t)c->n_tiles * ROPE_SUM_WORDS));
+    c->h_fq.assign(q, q + 6 * (size_t)n_frames);
+    c->n_frames = n_frames;
+    c->ftotal_loss = -1;
+    return ROPE_OK;
+}
+
+extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_render, int loss, uint64_t *sums_out)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "rope_eval_views: robot and camera must be set first");
+    if (c->n_frames < 1) ARG_FAIL(c, "rope_eval_views: no frames set");
+    if (!PV || !sums_out || K < 1) ARG_FAIL(c, "rope_eval_views: bad arguments");
+    if ((long long)K * c->n_frames > 65535) ARG_FAIL(c, "rope_eval_views: views x frames must not exceed 65535");
+    if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "rope_eval_views: n_render out of range");
+    if (loss != ROPE_LOSS_DEPTH && loss != ROPE_LOSS_TSWEEP && loss != ROPE_LOSS_CAMFULL) ARG_FAIL(c, "rope_eval_views: loss must be DEPTH, TSWEEP or CAMFULL");
+    if (loss == ROPE_LOSS_TSWEEP && !c->frames_t32) ARG_FAIL(c, "rope_eval_views: this loss needs the frames' float32 planes");
+    if (loss == ROPE_LOSS_CAMFULL && !c->frames_tl) ARG_FAIL(c, "rope_eval_views: this loss needs the frames' link planes");
+    for (size_t i = 0; i < 16 * (size_t)K; i++)
+        if (!std::isfinite(PV[i])) ARG_FAIL(c, "rope_eval_views: non-finite view matrix");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->n_frames, C = K * N;
+    // candidate (k, i) = view k, frame i: joint vector of frame i, scored against frame i's planes
+    std::vector<double> cand(6 * (size_t)C);
+    std::vector<int32_t> view_of((size_t)C), frame_of((size_t)C);
+    for (int k = 0; k < K; k++)
+        for (int i = 0; i < N; i++) {
+            std::memcpy(&cand[6 * ((size_t)k * N + i)], &c->h_fq[6 * (size_t)i], 6 * sizeof(double));
+            view_of[(size_t)k * N + i] = k;
+            frame_of[(size_t)k * N + i] = i;
+        }
+    int rc = upload_candidates(c, cand.data(), C, false);
+    if (rc) return rc;
+    if (K > c->views_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, realloc_dev(&c->d_PVs, 16 * (size_t)K)); c->views_cap = K; }
+    if (C > c->vf_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, realloc_dev(&c->d_view_of, (size_t)C));
+        HIP_TRY(c, realloc_dev(&c->d_frame_of, (size_t)C));
+        c->vf_cap = C;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_PVs, PV, 16 * (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_view_of, view_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_frame_of, frame_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const size_t plane = (size_t)c->fp.W * c->fp.H;
+    if (c->ftotal_loss != loss) {
+        // sums of every frame with nothing rendered: the raster launch only adds what the render changes
+        for (int i = 0; i < N; i++)
+            HIP_TRY(c, launch_empty(loss, c->stream, c->fp, c->d_ftq + (size_t)i * plane, c->frames_t32 ? c->d_ft32 + (size_t)i * plane : nullptr,
+                                    c->frames_tl ? c->d_ftl + (size_t)i * plane * ROPE_MAX_LINKS : nullptr, c->d_fempty,
+                                    c->d_ftotal + (size_t)i * ROPE_SUM_WORDS));
+        c->ftotal_loss = loss;
+    }
+    rc = enqueue_eval(c, n_render, loss, c->fp, (double)plane, nullptr, true);
+    if (rc) return rc;
+    std::vector<uint64_t> total((size_t)N * ROPE_SUM_WORDS);
+    HIP_TRY(c, hipMemcpyAsync(sums_out, c->d_sums, (size_t)C * ROPE_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(total.data(), c->d_ftotal, total.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool links = (loss == ROPE_LOSS_CAMFULL);
+    for (int k = 0; k < K; k++)
+        for (int i = 0; i < N; i++)
+            for (int w = 0; w < ROPE_SUM_WORDS; w++) {
+                uint64_t &o = sums_out[((size_t)k * N + i) * ROPE_SUM_WORDS + w];
+                const bool live = w < SUM_LINK0 || (links && w < SUM_LINK0 + 3 * n_render);
+                o = live ? o + total[(size_t)i * ROPE_SUM_WORDS + w] : 0;      // modulo 2^64, as the kernel's deltas are
+            }
     return ROPE_OK;
 }
 

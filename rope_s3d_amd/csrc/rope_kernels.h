@@ -80,6 +80,10 @@ struct RasterArgs {
     uint32_t *layers;                     // n_layers x n_tiles x (TILE_W*TILE_H) keys
     uint64_t *layer_sums;                 // n_layers x n_tiles x ROPE_SUM_WORDS: loss sums of the layer alone
     const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
+    // camera-pose path: planes of all frames back to back (frame stride H*W; tl: 6 per-link planes per frame,
+    // bit 40 = link mask, bits 0..38 = masked target depth) and each candidate's frame index
+    const uint64_t *tl;
+    const int32_t *frame_of;
     uint64_t *sums; uint32_t *key_out; uint8_t *cover;
     float *table;                         // MODE_TABLE: C x crop_h x crop_w sqrt-depth (crop = fp.r0..c1)
     // few candidates: the meshlets of a (tile, candidate) are split over `split` workgroups (grid z) that merge
@@ -89,14 +93,14 @@ struct RasterArgs {
 };
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
-                     const double *joint_axes, const double *PV, float *mvp, uint64_t *sums, uint32_t *mask_lo,
-                     uint32_t *mask_hi, int mask_words);
+                     const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                          const RasterArgs &a);
-hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,
+hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,
                         uint64_t *empty_sums, uint64_t *total);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err /* C + 2: errors, best error, best index */);

@@ -83,11 +83,14 @@ __device__ static inline void aff_mul(const double *A, const double *B, double *
 // One thread per candidate.  Writes n_render 4x4 float matrices.
 __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
-              const double *__restrict__ joint_axes, const double *__restrict__ PV, float *__restrict__ mvp,
-              uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words)
+              const double *__restrict__ joint_axes, const double *__restrict__ PV_all, const int32_t *__restrict__ view_of,
+              float *__restrict__ mvp, uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi,
+              int mask_words)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    // camera-pose path: every candidate names its own view matrix (camera_pose_prediction.py:116-124)
+    const double *__restrict__ PV = PV_all + (view_of ? 16 * (size_t)view_of[c] : 0);
     // first kernel of a pass: clear what the later kernels accumulate into (saves three memset launches)
     for (int k = 0; k < ROPE_SUM_WORDS; k++) sums[(size_t)c * ROPE_SUM_WORDS + k] = 0;
     for (int k = 0; k < mask_words; k++) { mask_lo[(size_t)c * mask_words + k] = 0; mask_hi[(size_t)c * mask_words + k] = 0; }
@@ -141,6 +144,10 @@ __device__ static inline uint64_t q32_of_f32(float z)
     return sh >= 0 ? (m << sh) : (sh > -64 ? (m >> -sh) : 0);
 }
 
+// floor(sqrt(x) * 2^32) for x given in Q32: sqrt(dq * 2^-32) * 2^32 = sqrt(dq) * 2^16; one correctly rounded
+// float64 square root (dq < 2^39 converts exactly), then truncation
+__device__ static inline uint64_t sqrt_q32(uint64_t dq) { return (uint64_t)(sqrt((double)dq) * 65536.0); }
+
 // NEG subtracts instead of adds (modulo 2^64): lets "sums(tile) - sums(base)" live in one set of registers
 template <bool NEG>
 __device__ static inline void acc(uint64_t &w, uint64_t x) { if (NEG) w -= x; else w += x; }
@@ -158,8 +165,8 @@ __device__ static inline void acc_sq(uint64_t *s, uint64_t dq)
 // Loss terms of one pixel given its z-buffer key.  `pix` indexes the H x W target planes.
 template <int LOSS, bool NEG = false>
 __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t *__restrict__ tq,
-                                          const float *__restrict__ t32, float c_num, float c_sum, float c_dif,
-                                          uint64_t *s)
+                                          const float *__restrict__ t32, const uint64_t *__restrict__ tl, size_t plane,
+                                          float c_num, float c_sum, float c_dif, uint64_t *s)
 {
     const bool empty = (key == KEY_EMPTY);
     float z = empty ? 0.0f : linear_depth(key >> 8, c_num, c_sum, c_dif);
@@ -172,6 +179,27 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
         return;
     }
     const uint64_t t = tq[pix];
+    if (LOSS == ROPE_LOSS_CAMFULL) {
+        // CameraPredictor._error (camera_pose_prediction.py:933-970): every difference enters as its square root;
+        // per link (base_link included) mask mismatches and the mean of sqrt|T_l - D*R_l| over its non-zero entries
+        const uint64_t T = t & 0x7FFFFFFFFFull, zq = q32_of_f32(z);
+        const uint64_t dq = T > zq ? T - zq : zq - T;
+        if (dq) { acc<NEG>(s[SUM_CNT], 1); acc<NEG>(s[SUM_S1], dq); acc<NEG>(s[SUM_AA], sqrt_q32(dq)); }
+        const int id = empty ? 255 : (int)(key & 0xFF);
+#pragma unroll
+        for (int l = 0; l < ROPE_MAX_LINKS; l++) {
+            if (l < n_render) {
+                const uint64_t tll = tl[(size_t)l * plane + pix];
+                const bool M = (tll >> 40) & 1, R = (id == l);
+                if (!M && !R && !(tll & 0x7FFFFFFFFFull)) continue;
+                const uint64_t a = tll & 0x7FFFFFFFFFull, b = R ? zq : 0;
+                const uint64_t dl = a > b ? a - b : b - a;
+                acc<NEG>(s[SUM_LINK0 + 3 * l], (uint64_t)(M != R));
+                if (dl) { acc<NEG>(s[SUM_LINK0 + 3 * l + 1], 1); acc<NEG>(s[SUM_LINK0 + 3 * l + 2], sqrt_q32(dl)); }
+            }
+        }
+        return;
+    }
     if (empty && t == 0) return;                  // nothing rendered, no target: every term is zero
     const uint64_t T = t & 0x7FFFFFFFFFull, zq = q32_of_f32(z);
     const uint64_t dq = T > zq ? T - zq : zq - T;
@@ -205,8 +233,10 @@ __device__ static inline bool pixel_active(int row, int col, int W, int H, int r
 template <int LOSS, bool DELTA>
 __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *__restrict__ base /* global, or nullptr = nothing */,
                                          int row0, int col0, const FrameParams &fp, int n_render,
-                                         const uint64_t *__restrict__ tq, const float *__restrict__ t32, uint64_t *lds_sums)
+                                         const uint64_t *__restrict__ tq, const float *__restrict__ t32,
+                                         const uint64_t *__restrict__ tl, uint64_t *lds_sums)
 {
+    const size_t plane = (size_t)fp.W * fp.H;
     uint64_t s[ROPE_SUM_WORDS];
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
@@ -223,20 +253,20 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
                 const int i = 4 * i4 + j, row = row0 + i / TILE_W, col = col0 + i % TILE_W;
                 if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
                 const size_t pix = (size_t)row * fp.W + col;
-                score_pixel<LOSS, false>(keys[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
-                score_pixel<LOSS, true>(bas[j], pix, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+                score_pixel<LOSS, false>(keys[j], pix, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
+                score_pixel<LOSS, true>(bas[j], pix, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
             }
         }
     } else {
         for (int i = threadIdx.x; i < TILE_W * TILE_H; i += blockDim.x) {
             int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
             if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-            score_pixel<LOSS>(KEY_EMPTY, (size_t)row * fp.W + col, n_render, tq, t32, fp.c_num, fp.c_sum, fp.c_dif, s);
+            score_pixel<LOSS>(KEY_EMPTY, (size_t)row * fp.W + col, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
         }
     }
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) {
-        const bool used = (LOSS == ROPE_LOSS_FULL) ? true : (k < SUM_LINK0);
+        const bool used = (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? true : (k < SUM_LINK0);
         if (used && s[k]) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)s[k]);
     }
 }
@@ -245,14 +275,14 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
 // (actual - empty) for the tiles it touches, finalize adds the frame total back.
 template <int LOSS>
 __global__ void __launch_bounds__(NTHREADS)
-empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *__restrict__ t32,
+empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *__restrict__ t32, const uint64_t *__restrict__ tl,
                   uint64_t *__restrict__ empty_sums /* n_tiles x SUM_WORDS */)
 {
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
     if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
     __syncthreads();
     int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, lds_sums);
+    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, tl, lds_sums);
     __syncthreads();
     if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
 }
@@ -489,12 +519,16 @@ __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
 template <int LOSS, int MODE>
-__global__ void __launch_bounds__(NTHREADS, LOSS == ROPE_LOSS_FULL ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
 raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 {
     const int n_render = ra.n_render;
-    const uint64_t *__restrict__ tq = ra.tq;
-    const float *__restrict__ t32 = ra.t32;
+    // camera-pose path: the candidate (= view x frame) names the frame whose target planes it is scored against
+    const size_t frame = (MODE == MODE_SCORE && ra.frame_of) ? (size_t)ra.frame_of[blockIdx.y] : 0;
+    const size_t plane = (size_t)fp.W * fp.H;
+    const uint64_t *__restrict__ tq = ra.tq ? ra.tq + frame * plane : nullptr;
+    const float *__restrict__ t32 = ra.t32 ? ra.t32 + frame * plane : nullptr;
+    const uint64_t *__restrict__ tl = ra.tl ? ra.tl + frame * plane * ROPE_MAX_LINKS : nullptr;
     __shared__ uint32_t tile[TILE_W * TILE_H];
     __shared__ float s_mvp[ROPE_MAX_LINKS * 16];
     __shared__ uint16_t s_list[MAX_MESHLETS];
@@ -803,7 +837,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) dst[i] = reinterpret_cast<const uint4 *>(tile)[i];
         // loss sums of the layer alone (relative to "nothing rendered"): every candidate on this layer starts from them
         if (ra.layer_sums) {
-            score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, lds_sums);
+            score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, tl, lds_sums);
             __syncthreads();
             if (tid < ROPE_SUM_WORDS) ra.layer_sums[slot * ROPE_SUM_WORDS + tid] = lds_sums[tid];
         }
@@ -843,7 +877,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         return;
     }
     if (fp.debug & 16) return;
-    score_tile<LOSS, true>(tile, from_gtile ? nullptr : layer_tile, row0, col0, fp, n_render, tq, t32, lds_sums);
+    score_tile<LOSS, true>(tile, from_gtile ? nullptr : layer_tile, row0, col0, fp, n_render, tq, t32, tl, lds_sums);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
         uint64_t delta = lds_sums[tid];
@@ -1008,11 +1042,11 @@ static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const R
 }
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
-                     const double *joint_axes, const double *PV, float *mvp, uint64_t *sums, uint32_t *mask_lo,
-                     uint32_t *mask_hi, int mask_words)
+                     const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words)
 {
-    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, mvp,
-                       sums, mask_lo, mask_hi, mask_words);
+    hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, view_of,
+                       mvp, sums, mask_lo, mask_hi, mask_words);
     return hipGetLastError();
 }
 
@@ -1042,19 +1076,21 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
     else if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_SCORE>(grid, st, fp, rp, a);
     else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_SCORE>(grid, st, fp, rp, a);
     else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a);
+    else if (loss == ROPE_LOSS_CAMFULL) launch_one<ROPE_LOSS_CAMFULL, MODE_SCORE>(grid, st, fp, rp, a);
     else launch_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a);
     return hipGetLastError();
 }
 
-hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32,
+hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,
                         uint64_t *empty_sums, uint64_t *total)
 {
     dim3 grid(fp.tiles_x * fp.tiles_y);
     switch (loss) {
-    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
-    case ROPE_LOSS_FULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_FULL>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
-    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_LOOKUP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
-    default: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, empty_sums); break;
+    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
+    case ROPE_LOSS_FULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_FULL>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
+    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_LOOKUP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
+    case ROPE_LOSS_CAMFULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_CAMFULL>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
+    default: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
     }
     hipLaunchKernelGGL(total_tiles_kernel, dim3(1), dim3(64), 0, st, empty_sums, fp.tiles_x * fp.tiles_y, total);
     return hipGetLastError();

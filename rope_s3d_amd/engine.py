@@ -12,7 +12,7 @@ import numpy as np
 from .build import LIB_PATH
 from .robot import RobotModel
 
-LOSS_DEPTH, LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP = 0, 1, 2, 3
+LOSS_DEPTH, LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, LOSS_CAMFULL = 0, 1, 2, 3, 4
 SUM_WORDS = 23
 Q32 = 4294967296.0
 TQ_MAX = (1 << 39) - 1
@@ -20,7 +20,8 @@ TQ_MAX = (1 << 39) - 1
 ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
-    'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip')
+    'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip',
+    'rope_set_frames', 'rope_eval_views')
 
 
 class EngineUnavailable(RuntimeError):
@@ -68,6 +69,8 @@ def load_library(path: str = None):
     lib.rope_debug_mvp.argtypes = [vp, vp, i32, i32]
     lib.rope_profile_eval.argtypes = [vp, i32, i32, vp, i32, vp]
     lib.rope_debug_skip.argtypes = [vp, i32]
+    lib.rope_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
     _lib = lib
     return lib
 
@@ -223,6 +226,34 @@ class Engine:
         self._check(self._lib.rope_coverage(self._ctx, _p(cand), len(cand), int(n_render), _p(cover)), 'rope_coverage')
         self.n_candidates = len(cand)
         return cover
+
+    # -- camera-pose path ------------------------------------------------------------------------
+    def set_frames(self, q, tq, t32=None, link_planes=None):
+        """N frames: joint vectors (N,6), uint64 depth planes (N,H,W), optional float32 planes (N,H,W) and per-link
+        planes (N,6,H,W) — the targets every candidate camera is scored against (rope_set_frames)."""
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 6)
+        n = len(q)
+        tq = np.ascontiguousarray(tq, np.uint64)
+        if tq.shape != (n, self.H, self.W):
+            raise ValueError(f"frame planes must be {(n, self.H, self.W)}, got {tq.shape}")
+        if t32 is not None:
+            t32 = np.ascontiguousarray(t32, np.float32)
+            if t32.shape != tq.shape:
+                raise ValueError("float32 frame planes have the wrong shape")
+        if link_planes is not None:
+            link_planes = np.ascontiguousarray(link_planes, np.uint64)
+            if link_planes.shape != (n, 6, self.H, self.W):
+                raise ValueError("link planes must be (N, 6, H, W)")
+        self._check(self._lib.rope_set_frames(self._ctx, n, _p(q), _p(tq), _p(t32), _p(link_planes)), 'rope_set_frames')
+        self.n_frames = n
+
+    def eval_views(self, PV, n_render: int, loss: int) -> np.ndarray:
+        """K candidate cameras (K,4,4 P·V) x the resident frames -> (K, N, 23) exact integer sums."""
+        PV = np.ascontiguousarray(PV, np.float64).reshape(-1, 4, 4)
+        sums = np.empty((len(PV), self.n_frames, SUM_WORDS), np.uint64)
+        self._check(self._lib.rope_eval_views(self._ctx, _p(PV), len(PV), int(n_render), int(loss), _p(sums)), 'rope_eval_views')
+        self.n_candidates = len(PV) * self.n_frames
+        return sums
 
     def debug_mvp(self, C_: int, n_render: int) -> np.ndarray:
         out = np.empty((C_, n_render, 16), np.float32)

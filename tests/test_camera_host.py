@@ -1,0 +1,95 @@
+"""CPU: host logic of the camera-pose predictors and the oracle's restatement of their reductions."""
+import numpy as np
+
+from oracle import camera_ref, oracle as orc
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
+from rope_s3d_amd.prediction import camera_pose_prediction as cpp
+from rope_s3d_amd.projection import Intrinsics, view_matrix
+
+import helpers
+
+
+def test_camera_matrices_agree_bitwise_and_with_closed_form():
+    intr = Intrinsics('640_480_color')
+    P = camera_ref.gl_projection(intr.fx, intr.fy, intr.cx, intr.cy, intr.width, intr.height, ZNEAR, ZFAR)
+    assert np.array_equal(P, intr.gl_projection(ZNEAR, ZFAR))
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        pose = np.array(DEFAULT_CAMERA_POSE, float) + rng.uniform(-.3, .3, 6)
+        assert np.array_equal(camera_ref.view_of_pose(pose), view_matrix(pose))
+    # default pose: camera at (0,-1.5,.75), roll = pi/2 -> looks along world +Y with world +Z up
+    V = camera_ref.view_of_pose(DEFAULT_CAMERA_POSE)
+    p_cam = V @ np.array([0.0, 0.0, 0.75, 1.0])               # a point 1.5 m in front of the camera
+    assert np.allclose(p_cam[:3], [0, 0, -1.5], atol=1e-12)
+    up = V[:3, :3] @ np.array([0, 0, 1.0])
+    assert np.allclose(up, [0, 1, 0], atol=1e-12)
+
+
+def test_stage_tables_match_between_product_and_oracle():
+    for a, b in ((cpp.modelless_stages(), camera_ref.modelless_stages()), (cpp.segmented_stages(), camera_ref.segmented_stages())):
+        assert len(a) == len(b)
+        for sa, sb in zip(a, b):
+            assert sa[0] == sb[0] and len(sa) == len(sb)
+            for x, y in zip(sa[1:], sb[1:]):
+                assert np.array_equal(np.asarray(x, object), np.asarray(y, object))
+    m = cpp.modelless_stages()
+    assert len(m) == 10 + 3 + 6 + 2 and [s[0] for s in m[13:16]] == ['zp_sweep', 'smartsweep', 'smartsweep']
+    assert m[14][3] == [False, False, False, False, False, True]      # p_fix was rebound to the yaw sweep (:96)
+    s = cpp.segmented_stages()
+    assert len(s) == 20 + 3 + 6 + 1 and s[24][3] == [False, False, False, False, True, False]
+
+
+def _scene(n_frames=2, seed=5):
+    rb = helpers.robot()
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    o = helpers.make_oracle(rb, intr, PV)
+    rng = np.random.default_rng(seed)
+    lim = rb.joint_limits
+    qs = rng.uniform(lim[:, 0], lim[:, 1], (n_frames, 6)) * np.array([1, 1, 1, 0, 0, 0])
+    tgt, ids = zip(*[o.render(q, 6) for q in qs])
+    return rb, intr, o, qs, np.stack(tgt).astype(np.float64), np.stack(ids)
+
+
+def test_integer_sums_track_the_literal_reductions():
+    """The fixed-point contract against the reference's float expressions (TF float32 / numpy float64)."""
+    rb, intr, o, qs, tgt, ids = _scene()
+    P = intr.gl_projection(ZNEAR, ZFAR)
+    names = rb.link_names[:6]
+    seg = [{n: {'mask': (ids[i] == l)} for l, n in enumerate(names) if (ids[i] == l).any()} for i in range(len(qs))]
+    pose = np.array(DEFAULT_CAMERA_POSE, float) + np.array([.03, -.02, .01, .004, -.006, .01])
+    depth, rid = [], []
+    for i, q in enumerate(qs):
+        o.PV = np.ascontiguousarray(P @ camera_ref.view_of_pose(pose))
+        d, r = o.render(q, 6)
+        depth.append(d)
+        rid.append(r)
+    depth, rid = np.stack(depth), np.stack(rid)
+
+    ref = camera_ref.CameraReference(o, P, 'modelless', qs, tgt)
+    assert abs(ref.error(pose) - camera_ref.modelless_error_literal(depth, tgt)) < 1e-6
+    ref = camera_ref.CameraReference(o, P, 'segmented', qs, tgt, seg, names)
+    blue = {n: l for l, n in enumerate(names)}                 # any injective labelling: use the link id itself
+    want = camera_ref.camfull_error_literal(rid, depth.astype(np.float64), tgt, ref.masked_targets, ref.target_masks, names, blue)
+    got = ref.error(pose)
+    assert abs(got - want) < 1e-6 * max(1.0, abs(want))
+    assert abs(ref.sweep_error(pose) - camera_ref.pooled_sweep_literal(depth, tgt)) < 1e-6
+
+
+def test_product_epilogues_equal_the_oracles():
+    rb, intr, o, qs, tgt, ids = _scene(3, seed=9)
+    P = intr.gl_projection(ZNEAR, ZFAR)
+    names = rb.link_names[:6]
+    seg = [{n: {'mask': (ids[i] == l)} for l, n in enumerate(names) if (ids[i] == l).any()} for i in range(len(qs))]
+    ref = camera_ref.CameraReference(o, P, 'segmented', qs, tgt, seg, names)
+    poses = np.array(DEFAULT_CAMERA_POSE, float) + np.random.default_rng(1).uniform(-.05, .05, (2, 6))
+    n_pix = float(tgt.shape[1] * tgt.shape[2])
+    full = np.stack([ref.frame_sums(p, 'full') for p in poses])
+    sweep = np.stack([ref.frame_sums(p, 'sweep') for p in poses])
+    flags = np.tile(ref.flags, (len(qs), 1))
+    assert np.array_equal(cpp.camfull_error(full, n_pix, flags), [ref.error(p) for p in poses])
+    assert np.array_equal(cpp.pooled_sweep_error(sweep, n_pix), [ref.sweep_error(p) for p in poses])
+    ml = camera_ref.CameraReference(o, P, 'modelless', qs, tgt)
+    assert np.array_equal(cpp.modelless_error(sweep, n_pix), [ml.error(p) for p in poses])
+    # planes as the product packs them == planes as the oracle packs them
+    planes = cpp.link_planes_of(ref.masked_targets[0], ref.target_masks[0], names, tgt.shape[1:])
+    assert np.array_equal(planes, ref.planes)

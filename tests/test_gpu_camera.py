@@ -1,0 +1,150 @@
+"""GPU: the camera-pose path (rope_set_frames / rope_eval_views and the two camera predictors) against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import camera_ref, oracle as orc
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
+from rope_s3d_amd.imgproc import resize_linear
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+TRUE_POSE = np.array(DEFAULT_CAMERA_POSE, float) + np.array([.06, -.05, .04, .01, -.015, .02])
+
+
+def _frames(renderer, rb, n, seed):
+    """n synthetic frames at the base resolution: the robot at random S/L/U angles seen from TRUE_POSE."""
+    rng = np.random.default_rng(seed)
+    lim = rb.joint_limits
+    qs = rng.uniform(lim[:, 0], lim[:, 1], (n, 6)) * np.array([1, 1, 1, 0, 0, 0])
+    renderer.setCameraPose(TRUE_POSE)
+    colors, depths = [], []
+    for q in qs:
+        renderer.setJointAngles(q)
+        c, d = renderer.render()
+        colors.append(c)
+        depths.append(d.astype(np.float64))
+    return qs, np.stack(colors), np.stack(depths)
+
+
+@pytest.fixture(scope='module')
+def big_renderer():
+    from rope_s3d_amd import Renderer
+    return Renderer('seg', DEFAULT_CAMERA_POSE, '640_480_color')
+
+
+def _oracle_side(rb, ds=4):
+    intr, PV = helpers.camera('640_480_color', ds=ds)
+    return intr, helpers.make_oracle(rb, intr, PV), intr.gl_projection(ZNEAR, ZFAR)
+
+
+def test_eval_views_sums_are_bit_exact(big_renderer):
+    from rope_s3d_amd import engine as eng
+    from rope_s3d_amd.prediction import camera_pose_prediction as cpp
+    rb = helpers.robot()
+    qs, colors, depths = _frames(big_renderer, rb, 3, 21)
+    intr, o, P = _oracle_side(rb)
+    tgt = np.stack([resize_linear(d, intr.width, intr.height) for d in depths])
+    small = [resize_linear(c, intr.width, intr.height) for c in colors]
+    names = rb.link_names[:6]
+    from rope_s3d_amd.segmentation import ColorSegmenter
+    segf = ColorSegmenter(['BG'] + names)
+    seg = []
+    for s in small:
+        r = segf(s)
+        seg.append({(['BG'] + names)[cid]: {'mask': r['masks'][..., k]} for k, cid in enumerate(r['class_ids'])})
+    ref = camera_ref.CameraReference(o, P, 'segmented', qs, tgt, seg, names)
+
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(P @ camera_ref.view_of_pose(DEFAULT_CAMERA_POSE), intr.width, intr.height, ZNEAR, ZFAR)
+    e.set_frames(qs, np.stack([eng.pack_target(d) for d in tgt]), tgt.astype(np.float32),
+                 np.tile(ref.planes[None], (3, 1, 1, 1)))
+    rng = np.random.default_rng(4)
+    poses = np.array(DEFAULT_CAMERA_POSE, float) + rng.uniform(-.15, .15, (5, 6))
+    poses[0] = TRUE_POSE
+    PV = np.stack([P @ camera_ref.view_of_pose(p) for p in poses])
+    for K in (5, 1):            # 15 candidates: one workgroup per tile; 3 candidates: the small-batch split path
+        got_full = e.eval_views(PV[:K], 6, eng.LOSS_CAMFULL)
+        got_sweep = e.eval_views(PV[:K], 6, eng.LOSS_TSWEEP)
+        for k in range(K):
+            assert np.array_equal(got_full[k], ref.frame_sums(poses[k], 'full')), f"CAMFULL sums, view {k}"
+            want = ref.frame_sums(poses[k], 'sweep')
+            assert np.array_equal(got_sweep[k][:, :5], want[:, :5]), f"sweep sums, view {k}"
+    # at the true pose the render reproduces the target up to the 4x down-sampling
+    n_pix = float(intr.width * intr.height)
+    errs = cpp.camfull_error(e.eval_views(PV, 6, eng.LOSS_CAMFULL), n_pix, np.tile(ref.flags, (3, 1)))
+    assert int(np.argmin(errs)) == 0
+
+
+def test_eval_views_argument_errors(big_renderer):
+    from rope_s3d_amd import engine as eng
+    rb = helpers.robot()
+    intr, o, P = _oracle_side(rb)
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(P @ camera_ref.view_of_pose(DEFAULT_CAMERA_POSE), intr.width, intr.height, ZNEAR, ZFAR)
+    PV = (P @ camera_ref.view_of_pose(DEFAULT_CAMERA_POSE))[None]
+    e.n_frames = 1
+    with pytest.raises(eng.EngineError, match='no frames'):
+        e.eval_views(PV, 6, eng.LOSS_TSWEEP)
+    tq = np.zeros((1, intr.height, intr.width), np.uint64)
+    e.set_frames(np.zeros((1, 6)), tq)
+    with pytest.raises(eng.EngineError, match='float32'):
+        e.eval_views(PV, 6, eng.LOSS_TSWEEP)
+    with pytest.raises(eng.EngineError, match='link planes'):
+        e.eval_views(PV, 6, eng.LOSS_CAMFULL)
+    with pytest.raises(eng.EngineError, match='loss'):
+        e.eval_views(PV, 6, eng.LOSS_LOOKUP)
+    bad = PV.copy()
+    bad[0, 0, 0] = np.nan
+    with pytest.raises(eng.EngineError, match='non-finite'):
+        e.eval_views(bad, 6, eng.LOSS_DEPTH)
+    s = e.eval_views(PV, 6, eng.LOSS_DEPTH)          # depth-only sums against an all-zero target: every drawn sample counts
+    d, _ = o.render(np.zeros(6), 6)
+    assert s.shape == (1, 1, 23) and int(s[0, 0, 0]) == int((d != 0).sum())
+
+
+def test_modelless_predictor_trace_matches_sequential_reference(big_renderer):
+    from rope_s3d_amd import ModellessCameraPredictor
+    rb = helpers.robot()
+    qs, colors, depths = _frames(big_renderer, rb, 2, 33)
+    start = np.array(DEFAULT_CAMERA_POSE, float)
+    p = ModellessCameraPredictor(start, 4, base_intrinsics='640_480_color')
+    got = p.run(colors, depths, qs)
+    intr, o, P = _oracle_side(rb)
+    tgt = np.stack([resize_linear(d, intr.width, intr.height) for d in depths])
+    ref = camera_ref.CameraReference(o, P, 'modelless', qs, tgt)
+    want, trace = ref.run(start)
+    assert len(trace) == len(p.trace)
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert k_ref == k_got and np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
+    assert p.evaluations == ref.evaluations
+    # The reference's score is mean * -std (the `*-` of camera_pose_prediction.py:405), so its argmin walks towards
+    # LARGER differences: no convergence to TRUE_POSE can be asserted, only that the machine minimised its own metric.
+    assert p.error_at(got) <= p.error_at(start)
+
+
+def test_segmented_predictor_trace_matches_sequential_reference(big_renderer):
+    from rope_s3d_amd import CameraPredictor
+    from rope_s3d_amd.segmentation import ColorSegmenter
+    rb = helpers.robot()
+    names = rb.link_names[:6]
+    qs, colors, depths = _frames(big_renderer, rb, 2, 34)
+    start = np.array(DEFAULT_CAMERA_POSE, float)
+    segf = ColorSegmenter(['BG'] + names, split_instances=True)
+    p = CameraPredictor(start, 4, base_intrinsics='640_480_color', segmenter=segf)
+    got = p.run(colors, depths, qs)
+    intr, o, P = _oracle_side(rb)
+    tgt = np.stack([resize_linear(d, intr.width, intr.height) for d in depths])
+    seg = [p._reorganize_by_link(segf(resize_linear(c, intr.width, intr.height).astype(np.uint8))) for c in colors]
+    ref = camera_ref.CameraReference(o, P, 'segmented', qs, tgt, seg, names)
+    want, trace = ref.run(start)
+    assert len(trace) == len(p.trace)
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert k_ref == k_got and np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
+    # no convergence claim: the stage list interleaves _error (minimised) with the pooled mean * -std sweeps, whose
+    # argmin prefers larger differences (:846); agreement with the sequential restatement is the whole test
+    assert p.evaluations == ref.evaluations
