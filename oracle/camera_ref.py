@@ -250,6 +250,31 @@ class CameraReference:
         m1, sd = sweep_mean_std(pooled, self.n_pix * self.N)
         return float(m1 * -sd)
 
+    def spiral(self, batch=10000, r_limits=(1, 3), shells=25, per_round=75, z_limits=(0, 1), turns=10):
+        """SpiralRenderer.run (:453-497) with ModellessCameraPredictor._error on a 2-D depth: one render per pose at
+        the LAST frame's joint vector, broadcast against all frame targets (:410-424)."""
+        r_min, r_max, z_min, z_max = min(r_limits), max(r_limits), min(z_limits), max(z_limits)
+        num_per_spiral = turns * per_round
+        base_spiral = np.zeros((num_per_spiral, 6))
+        angles_partial = np.linspace(0, 2 * np.pi, per_round)
+        angles_full = np.tile(angles_partial, turns)
+        base_spiral[:, 5] = 2 * np.pi - angles_full
+        base_spiral[:, 0] = -np.sin(angles_full)
+        base_spiral[:, 1] = -np.cos(angles_full)
+        base_spiral[:, 2] = np.linspace(z_min, z_max, num_per_spiral)
+        full_space = np.tile(base_spiral, (shells, 1))
+        r_partial = np.linspace(r_min, r_max, shells)
+        r_full = np.repeat(r_partial, num_per_spiral)
+        full_space[:, 0] *= r_full
+        full_space[:, 1] *= r_full
+        errors = np.zeros(full_space.shape[0])
+        for k, pose in enumerate(full_space):
+            key = self._render_key(pose, self.N - 1)
+            s = np.stack([self.o.sums(key, orc.LOSS_TSWEEP, 6, self.tq[i], self.t32[i]) for i in range(self.N)])
+            m1, sd = sweep_mean_std(s, self.n_pix)
+            errors[k] = np.mean(np.power(1.1, m1 * -sd))
+        return full_space[errors.argmin()], errors
+
     def run(self, starting_pose):
         pose = np.array(starting_pose, dtype=float)
         learning_rates = np.zeros(6)
@@ -258,7 +283,9 @@ class CameraReference:
         div = None
         trace = []
         for stage in self.stages:
-            if stage[0] == 'descent':
+            if stage[0] == 'spiral' and self.mode == 'modelless':
+                pose, _ = self.spiral(*stage[1:])
+            elif stage[0] == 'descent':
                 for i in range(6):
                     if stage[5][i] is not None:
                         learning_rates[i] = stage[5][i]

@@ -192,7 +192,11 @@ class _CameraStageMachine:
 
         for stage in self.stages:
             kind = stage[0]
-            if kind == 'descent':
+            if kind == 'spiral' and self.zp_div_from_stage:
+                # global search over shells of spiralling view points (:174-181); only the model-less predictor has it
+                pose = SpiralRenderer(self.renderer, self._spiral_errors, None, *stage[1:]).run()
+
+            elif kind == 'descent':
                 for i in range(6):
                     if stage[5][i] is not None:
                         learning_rates[i] = stage[5][i]
@@ -299,6 +303,40 @@ class _CameraStageMachine:
         return og_images, target_depths, pose
 
 
+class SpiralRenderer:
+    """Exhaustive search over view points on `shells` cylinders of radius r_limits, each a spiral of `turns` x
+    `per_round` poses climbing through z_limits and looking at the axis (:434-497).  The reference renders and scores
+    the poses one by one and plots the errors; here `error_func` takes the whole pose array (chunks of `batch`)."""
+
+    def __init__(self, renderer, error_func, render_func=None, batch=10000, r_limits=[1, 3], shells=25, per_round=75,
+                 z_limits=[0, 1], turns=10) -> None:
+        self.renderer, self.error, self.render_func = renderer, error_func, render_func
+        self.batch = batch
+        self.r_min, self.r_max = min(r_limits), max(r_limits)
+        self.shells, self.per_round, self.turns = shells, per_round, turns
+        self.z_min, self.z_max = min(z_limits), max(z_limits)
+
+    def poses(self) -> np.ndarray:
+        num_per_spiral = self.turns * self.per_round
+        base_spiral = np.zeros((num_per_spiral, 6))
+        angles_full = np.tile(np.linspace(0, 2 * np.pi, self.per_round), self.turns)
+        base_spiral[:, 5] = 2 * np.pi - angles_full
+        base_spiral[:, 0] = -np.sin(angles_full)
+        base_spiral[:, 1] = -np.cos(angles_full)
+        base_spiral[:, 2] = np.linspace(self.z_min, self.z_max, num_per_spiral)
+        full_space = np.tile(base_spiral, (self.shells, 1))
+        r_full = np.repeat(np.linspace(self.r_min, self.r_max, self.shells), num_per_spiral)
+        full_space[:, 0] *= r_full
+        full_space[:, 1] *= r_full
+        return full_space
+
+    def run(self) -> np.ndarray:
+        full_space = self.poses()
+        errors = np.concatenate([self.error(full_space[i:i + self.batch]) for i in range(0, len(full_space), self.batch)])
+        self.errors = errors
+        return full_space[errors.argmin()].copy()
+
+
 class ModellessCameraPredictor(_CameraStageMachine):
     """Camera pose from depth alone: every frame's render against its depth map, no segmentation (:28-431)."""
 
@@ -314,8 +352,8 @@ class ModellessCameraPredictor(_CameraStageMachine):
         og_images, target_depths, pose = self._start(og_images, target_depths, robot_poses, starting_camera_pose)
         self._tgt_depths = self._batch_downsample(target_depths, self.ds_factor)
         self._n_pix = float(self._tgt_depths.shape[1] * self._tgt_depths.shape[2])
-        self.engine.set_frames(self.robot_poses, np.stack([pack_target(d) for d in self._tgt_depths]),
-                               self._tgt_depths.astype(np.float32))
+        self._frame_planes = (np.stack([pack_target(d) for d in self._tgt_depths]), self._tgt_depths.astype(np.float32))
+        self.engine.set_frames(self.robot_poses, *self._frame_planes)
         if self.stages is None:
             self._setStages()
         return self.run_stages(pose)
@@ -324,6 +362,16 @@ class ModellessCameraPredictor(_CameraStageMachine):
         return modelless_error(self._sums(poses, LOSS_TSWEEP), self._n_pix)
 
     _sweep_errors = _errors       # _error treats a (div, poses, H, W) stack the same way (:393-408)
+
+    def _spiral_errors(self, poses):
+        """What SpiralRenderer.run feeds `_error`: ONE render per pose — `renderer.render()` after do_renders_at_pose
+        leaves the robot at the last frame's joint vector (:485-488) — broadcast against every frame's target (:410-424)."""
+        tq, t32 = self._frame_planes
+        self.engine.set_frames(np.tile(self.robot_poses[-1], (self.number_of_poses, 1)), tq, t32)
+        try:
+            return self._errors(poses)
+        finally:
+            self.engine.set_frames(self.robot_poses, tq, t32)
 
 
 class CameraPredictor(_CameraStageMachine):

@@ -148,3 +148,24 @@ def test_segmented_predictor_trace_matches_sequential_reference(big_renderer):
     # no convergence claim: the stage list interleaves _error (minimised) with the pooled mean * -std sweeps, whose
     # argmin prefers larger differences (:846); agreement with the sequential restatement is the whole test
     assert p.evaluations == ref.evaluations
+
+
+def test_spiral_search_matches_reference(big_renderer):
+    """The 'spiral' stage (not in the active lists): every view point of a small spiral, robot held at the last
+    frame's joints, scored against all frames — errors equal the sequential restatement to the bit."""
+    from rope_s3d_amd import ModellessCameraPredictor
+    rb = helpers.robot()
+    qs, colors, depths = _frames(big_renderer, rb, 2, 35)
+    spiral = ['spiral', 10000, [1, 3], 3, 7, [0, 1], 2]         # batch, r_limits, shells, per_round, z_limits, turns
+    p = ModellessCameraPredictor(DEFAULT_CAMERA_POSE, 4, base_intrinsics='640_480_color')
+    p.stages = [spiral, ('tensorsweep', 5, .05, [True, False, False, False, False, True])]
+    got = p.run(colors, depths, qs)
+    intr, o, P = _oracle_side(rb)
+    tgt = np.stack([resize_linear(d, intr.width, intr.height) for d in depths])
+    ref = camera_ref.CameraReference(o, P, 'modelless', qs, tgt, stages=p.stages)
+    best, errors = ref.spiral(*spiral[1:])
+    assert np.array_equal(p.trace[0][1], best)
+    want, trace = ref.run(DEFAULT_CAMERA_POSE)
+    assert np.array_equal(got, want)
+    # the frames are restored after the spiral: the sweep that follows scores each frame at its own joints
+    assert np.array_equal(p.trace[1][1], trace[1][1])
