@@ -11,10 +11,10 @@ namespace rope {
 #define ROPE_TILE_W 128
 #endif
 #ifndef ROPE_TILE_H
-#define ROPE_TILE_H 48
+#define ROPE_TILE_H 96
 #endif
 #ifndef ROPE_NWAVES
-#define ROPE_NWAVES 8
+#define ROPE_NWAVES 12                      // 2 workgroups x 12 waves per CU = 6 waves per SIMD, 81.5 KB of LDS each
 #endif
 #ifndef ROPE_MIN_WAVES_PER_SIMD
 #define ROPE_MIN_WAVES_PER_SIMD 6
@@ -35,7 +35,10 @@ constexpr int NTHREADS = NWAVES * 64;
 constexpr int SMALL_TRI_COLS = ROPE_SMALL_TRI_COLS;
 constexpr int SMALL_TRI_ROWS = ROPE_SMALL_TRI_ROWS;   // boxes up to 4 samples wide and this many rows are walked by one lane
 constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet list in LDS
-constexpr int MESHLET_MAX_VERTS = 128;
+#ifndef ROPE_MESHLET_MAX_VERTS
+#define ROPE_MESHLET_MAX_VERTS 64
+#endif
+constexpr int MESHLET_MAX_VERTS = ROPE_MESHLET_MAX_VERTS;
 constexpr int MESHLET_MAX_TRIS = 128;
 constexpr int COMPACT_PX = 60;            // meshlets no larger than this on screen take the 32-bit triangle set-up
 constexpr int MAX_MASK_WORDS = 256;        // tile-mask words per candidate (8192 tiles)

@@ -535,13 +535,17 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __shared__ int s_count;
     __shared__ SVert s_vert[NWAVES][MESHLET_MAX_VERTS];
     __shared__ int s_qoff[NWAVES][64];
-    __shared__ unsigned long long s_qmask[NWAVES][64];
+    __shared__ unsigned long long s_qmask[NWAVES][TILE_H > 64 ? TILE_H : 64];   // one word per chunk of 64 row items: at most 64 triangles x TILE_H rows
     __shared__ int s_next;
     __shared__ uint32_t s_keep[NWAVES][MESHLET_MAX_TRIS];
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_id = blockIdx.x;
+    // Workgroups go to the 8 XCDs round-robin by linear id, i.e. by (row * n_tiles + blockIdx.x) mod 8: with an even
+    // tile count a given screen tile would only ever meet 4, 2 or 1 of them, and the few tiles that hold the robot
+    // would pile up there.  Rotating the tile index by a per-row hash spreads every tile over all XCDs.
+    const int n_tiles_all = fp.tiles_x * fp.tiles_y;
+    const int tile_id = (int)((blockIdx.x + ((blockIdx.y * 0x9E3779B1u) >> 12)) % (unsigned)n_tiles_all);
     const int cand = (MODE == MODE_LAYER) ? ra.cand_of_row[blockIdx.y] : (int)blockIdx.y;
     const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
     const int col0 = tx * TILE_W, row0 = ty * TILE_H;
@@ -711,7 +715,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             const int excl = incl - rows;
             const int qpos = __popcll(qmask & ((1ull << lane) - 1));
             const int nchunks = (total + 63) >> 6;
-            if (lane < nchunks) wmask[lane] = 0;
+            for (int i = lane; i < nchunks; i += 64) wmask[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

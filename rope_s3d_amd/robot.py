@@ -20,8 +20,8 @@ import os as _os
 
 # Measured on the bench workload: region-grown patches of <=128 triangles over <=64 vertices
 # (one vertex-shading iteration per wave, 1.8 cm median radius) beat Morton runs of 128/128 by 8 %.
-MESHLET_MAX_TRIS = int(_os.environ.get('ROPE_MESHLET_TRIS', 128))      # engine limit: 128
-MESHLET_MAX_VERTS = int(_os.environ.get('ROPE_MESHLET_VERTS', 64))     # engine limit: 128
+MESHLET_MAX_TRIS = int(_os.environ.get('ROPE_MESHLET_TRIS', 128))      # engine limit: 64 (rope_kernels.h)
+MESHLET_MAX_VERTS = int(_os.environ.get('ROPE_MESHLET_VERTS', 64))     # engine limit: 64 (rope_kernels.h)
 
 
 def _rpy_matrix(rpy) -> np.ndarray:
