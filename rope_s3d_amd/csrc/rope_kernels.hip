@@ -230,21 +230,34 @@ __device__ static inline bool pixel_active(int row, int col, int W, int H, int r
 // DELTA = true: sums(tile) - sums(base tile), which only the samples whose key differs contribute to —
 // all others are skipped without touching the target planes.  Arithmetic is
 // modulo 2^64, the frame total of the "nothing rendered" sums is added back by finalize_argmin_kernel.
+// Rows [r_lo, r_hi] and 4-sample column groups [g_lo, g_hi] of a tile that a launch may have drawn into.
+struct TileRect { int r_lo, r_hi, g_lo, g_hi; };
+
 template <int LOSS, bool DELTA>
 __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *__restrict__ base /* global, or nullptr = nothing */,
                                          int row0, int col0, const FrameParams &fp, int n_render,
                                          const uint64_t *__restrict__ tq, const float *__restrict__ t32,
-                                         const uint64_t *__restrict__ tl, uint64_t *lds_sums)
+                                         const uint64_t *__restrict__ tl, uint64_t *lds_sums, const TileRect rc)
 {
     const size_t plane = (size_t)fp.W * fp.H;
     uint64_t s[ROPE_SUM_WORDS];
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
     if (DELTA) {
-        // only samples whose key differs from the base tile (the shared layer, or nothing) change the sums
-        for (int i4 = threadIdx.x; i4 < TILE_W * TILE_H / 4; i4 += blockDim.x) {
-            const uint4 k4 = reinterpret_cast<const uint4 *>(tile)[i4];
+        // Only samples whose key differs from the base tile (the shared layer, or nothing) change the sums, and only
+        // the rectangle this launch could draw into can hold any.  The z-test is a minimum over keys, so the tile
+        // holds this launch's own samples and min(tile, base) is the finished image: the base is never copied to LDS.
+        const int gw = rc.g_hi - rc.g_lo + 1;
+        int sh = 0;
+        while ((1 << sh) < gw) sh++;                       // lanes per row: the next power of two (shifts, no division)
+        const int n_items = (rc.r_hi - rc.r_lo + 1) << sh;
+        for (int it = threadIdx.x; it < n_items; it += blockDim.x) {
+            const int g = rc.g_lo + (it & ((1 << sh) - 1));
+            if (g > rc.g_hi) continue;
+            const int i4 = (rc.r_lo + (it >> sh)) * (TILE_W / 4) + g;
+            uint4 k4 = reinterpret_cast<const uint4 *>(tile)[i4];
             const uint4 b4 = base ? reinterpret_cast<const uint4 *>(base)[i4] : make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
+            k4.x = min(k4.x, b4.x); k4.y = min(k4.y, b4.y); k4.z = min(k4.z, b4.z); k4.w = min(k4.w, b4.w);
             if (k4.x == b4.x && k4.y == b4.y && k4.z == b4.z && k4.w == b4.w) continue;
             const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w}, bas[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -264,10 +277,20 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
             score_pixel<LOSS>(KEY_EMPTY, (size_t)row * fp.W + col, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
         }
     }
+    // one LDS atomic per word and wave: the partial sums (modulo 2^64) are added up across the lanes first, and
+    // waves that met no sample skip the whole step
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < ROPE_SUM_WORDS; k++) any = any || s[k] != 0;
+    if (__ballot(any) == 0) return;
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) {
         const bool used = (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? true : (k < SUM_LINK0);
-        if (used && s[k]) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)s[k]);
+        if (!used) continue;
+        uint64_t v = s[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)v);
     }
 }
 
@@ -282,7 +305,7 @@ empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *
     if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
     __syncthreads();
     int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, tl, lds_sums);
+    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, tl, lds_sums, TileRect{0, TILE_H - 1, 0, TILE_W / 4 - 1});
     __syncthreads();
     if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
 }
@@ -588,11 +611,13 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     // --- tile initialisation (a copy of the layer tile, or "empty"), link matrices, and the list of meshlets whose
     // screen box meets this tile: all in one phase so that the global loads overlap
     if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
-    if (layer_tile) {
+    if (from_gtile) {
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
             reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(layer_tile)[i];
     } else {
-        for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) tile[i] = KEY_EMPTY;
+        // the shared layer is not copied in: depth testing is a minimum, so it is merged where the tile is consumed
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
+            reinterpret_cast<uint4 *>(tile)[i] = make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
     }
     {
         const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
@@ -610,6 +635,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     }
     __syncthreads();
     const int n_list = s_count;
+    const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1};
     if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile) && !from_gtile) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
         if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
@@ -841,7 +867,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) dst[i] = reinterpret_cast<const uint4 *>(tile)[i];
         // loss sums of the layer alone (relative to "nothing rendered"): every candidate on this layer starts from them
         if (ra.layer_sums) {
-            score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, tl, lds_sums);
+            score_tile<LOSS, true>(tile, nullptr, row0, col0, fp, n_render, tq, t32, tl, lds_sums, rc);
             __syncthreads();
             if (tid < ROPE_SUM_WORDS) ra.layer_sums[slot * ROPE_SUM_WORDS + tid] = lds_sums[tid];
         }
@@ -861,8 +887,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         float *dst = ra.table + (size_t)cand * cw * ch;
         for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS) {
             const int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
-            if (tile[i] == KEY_EMPTY || !pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-            dst[(size_t)(row - fp.r0) * cw + (col - fp.c0)] = sqrtf(linear_depth(tile[i] >> 8, fp.c_num, fp.c_sum, fp.c_dif));
+            const uint32_t k = layer_tile ? min(tile[i], layer_tile[i]) : tile[i];
+            if (k == KEY_EMPTY || !pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
+            dst[(size_t)(row - fp.r0) * cw + (col - fp.c0)] = sqrtf(linear_depth(k >> 8, fp.c_num, fp.c_sum, fp.c_dif));
         }
         return;
     }
@@ -881,7 +908,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         return;
     }
     if (fp.debug & 16) return;
-    score_tile<LOSS, true>(tile, from_gtile ? nullptr : layer_tile, row0, col0, fp, n_render, tq, t32, tl, lds_sums);
+    score_tile<LOSS, true>(tile, from_gtile ? nullptr : layer_tile, row0, col0, fp, n_render, tq, t32, tl, lds_sums, rc);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
         uint64_t delta = lds_sums[tid];
