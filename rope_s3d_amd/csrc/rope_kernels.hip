@@ -506,18 +506,7 @@ __device__ static inline void depth_test_write(uint32_t *tile, int u, int v, con
         atomicMin(&tile[(TILE_H - 1 - v) * TILE_W + u], (d24 << 8) | link);
 }
 
-// smallest u with A*u >= n (A > 0), estimate by float then exact fix-up; clamped to [-5, TILE_W+4]
-__device__ static inline int ceil_div_pos(int32_t n, int32_t A, float rcpA)
-{
-    float q = ceilf((float)n * rcpA);
-    q = fminf(fmaxf(q, -3.0f), (float)(TILE_W + 2));
-    int u = (int)q;                                  // within 1 of the answer when that lies in range
-    u += (__mul24(A, u) < n);
-    u -= (__mul24(A, u - 1) >= n);
-    return u;
-}
-
-// largest u with A*u <= n (A > 0)
+// largest u with A*u <= n (A > 0): float estimate, then exact fix-up by one either way; clamped to [-4, TILE_W+3]
 __device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
 {
     float q = floorf((float)n * rcpA);
@@ -528,13 +517,20 @@ __device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
     return u;
 }
 
-// Samples of row v covered by the half-space: narrows [lo,hi].
+static_assert(TILE_W <= 256 && TILE_H <= 256, "row-pass items carry tile coordinates in 8 bits");
+
+// Samples of row v covered by the half-space: narrows [lo,hi].  One code path for both signs of A (the lanes of
+// a wave hold edges of every orientation): A > 0: u >= ceil(n/A) = floor((n+A-1)/A);  A < 0: u <= floor(-n/-A).
 __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
 {
-    const int32_t n = e.K - __mul24(e.B, v);       // A*u >= n   (|B| < 2^22, 0 <= v < TILE_H)
-    if (e.A > 0) lo = max(lo, ceil_div_pos(n, e.A, __builtin_amdgcn_rcpf((float)e.A)));
-    else if (e.A < 0) hi = min(hi, floor_div_pos(-n, -e.A, __builtin_amdgcn_rcpf((float)(-e.A))));
-    else if (n > 0) hi = -1;
+    const int32_t n = e.K - __mul24(e.B, v);       // A*u >= n   (|B| < 2^22, 0 <= v < TILE_H, |K| <= 2^30)
+    const bool neg = e.A < 0, zero = e.A == 0;
+    const int32_t Aa = zero ? 1 : abs(e.A);
+    const int32_t m = neg ? -n : n + Aa - 1;
+    const int q = floor_div_pos(m, Aa, __builtin_amdgcn_rcpf((float)Aa));
+    lo = (neg || zero) ? lo : max(lo, q);
+    hi = neg ? min(hi, q) : hi;
+    hi = (zero && n > 0) ? -1 : hi;
 }
 
 
@@ -661,7 +657,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             // what a queued triangle's owner lane keeps for the lanes that will take its rows
             Edge q0 = {0, 0, 0}, q1 = {0, 0, 0}, q2 = {0, 0, 0};
             Plane qpl = {0.0f, 0.0f, 0.0f};
-            int q_ulo = 0, q_uhi = -1, q_v0 = 0, q_dxa = 0, q_dya = 0;
+            // box and link in one word (u_lo | u_hi << 8 | v0 << 16 | link << 24), anchor offsets in another (each within
+            // 16 bits: edges reach less than 16384 px here and the box meets the tile)
+            int q_box = 0, q_anchor = 0;
             if (lane < n_active) {
                 const SVert a = pa, b = pb, c = pc;
                 const uint32_t l = plink;
@@ -720,8 +718,8 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                         } else {
                             rows = h;
                             q0 = e0; q1 = e1; q2 = e2; qpl = pl;
-                            q_ulo = x0 - col0; q_uhi = x1 - col0; q_v0 = y0 - tf.vy0;
-                            q_dxa = col0 - pxa; q_dya = tf.vy0 - pya;
+                            q_box = (x0 - col0) | ((x1 - col0) << 8) | ((y0 - tf.vy0) << 16) | ((int)l << 24);
+                            q_anchor = ((col0 - pxa) & 0xFFFF) | ((tf.vy0 - pya) << 16);
                         }
                     }
                 }
@@ -767,9 +765,10 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 e2.A = __shfl(q2.A, src, 64); e2.B = __shfl(q2.B, src, 64); e2.K = __shfl(q2.K, src, 64);
                 Plane pl;
                 pl.gx = __shfl(qpl.gx, src, 64); pl.gy = __shfl(qpl.gy, src, 64); pl.dc = __shfl(qpl.dc, src, 64);
-                int ulo = __shfl(q_ulo, src, 64), uhi = __shfl(q_uhi, src, 64);
-                const int v0q = __shfl(q_v0, src, 64), dxa = __shfl(q_dxa, src, 64), dya = __shfl(q_dya, src, 64);
-                const uint32_t lq = (uint32_t)__shfl((int)plink, src, 64);
+                const int box = __shfl(q_box, src, 64), anchor = __shfl(q_anchor, src, 64);
+                int ulo = box & 0xFF, uhi = (box >> 8) & 0xFF;
+                const int v0q = (box >> 16) & 0xFF, dxa = (int)(short)(anchor & 0xFFFF), dya = anchor >> 16;
+                const uint32_t lq = (uint32_t)box >> 24;
                 if (item < total) {
                     const int v = v0q + (item - (so & 0xFFFF));
                     clip_span(e0, v, ulo, uhi);
