@@ -74,6 +74,8 @@ def segment_targets(seg: dict, target_depth: np.ndarray, lookup_links) -> np.nda
 
 class Predictor:
 
+    SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
+
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
                  ds_factor: int = 8,
@@ -289,28 +291,52 @@ class Predictor:
                 lr[i] = stage.init_rate[i]
         n = stage.to_render
         over_err = under_err = np.inf
+        joints = [int(j) for j in np.where(stage.joints)[0]]
         with np.errstate(all='ignore'):
             for _ in range(stage.its):
-                for idx in np.where(stage.joints)[0]:
+                # Learning rates of the whole iteration first: a joint's rate depends on its own angle and on the
+                # history, and neither changes before that joint's turn (predict.py:184-187).
+                for idx in joints:
                     if abs(np.mean(history, 0)[idx] - angles[idx]) <= lr[idx]:
                         lr[idx] *= stage.rate_redux
                     lr = np.max((lr, self.min_ang_inc), 0)
-
-                    under = angles.copy()
-                    under[idx] -= lr[idx]
-                    over = under.copy()
-                    over[idx] += 2 * lr[idx]
-                    ok_u = limits[idx][0] <= under[idx] <= limits[idx][1]
-                    ok_o = limits[idx][0] <= over[idx] <= limits[idx][1]
-                    batch = [c for c, ok in ((under, ok_u), (over, ok_o)) if ok]
-                    errs = self._errors(n, np.array(batch)) if batch else []
-                    under_err = errs.pop(0) if ok_u else np.inf
-                    over_err = errs.pop(0) if ok_o else np.inf
-
-                    if over_err < under_err:                        # ties and NaN: stay (predict.py:212-215)
-                        angles[idx] += lr[idx]
-                    elif over_err > under_err:
-                        angles[idx] -= lr[idx]
+                # The reference evaluates under/over of one joint, decides, moves on: 2 renders at a time, each waiting
+                # for the last.  Here up to SPECULATE joints go out as ONE batch holding the under/over pair of every
+                # state the earlier decisions can lead to (+lr, -lr, stay: 2, 6, 18 rows); the decisions are then read
+                # off the results in the reference's order.  Rows are independent, so the path taken sees the same bits.
+                for g in range(0, len(joints), self.SPECULATE):
+                    group = joints[g:g + self.SPECULATE]
+                    frontier, rows, index = [angles.copy()], [], {}
+                    for level, idx in enumerate(group):
+                        nxt = []
+                        for k, state in enumerate(frontier):
+                            under = state.copy()
+                            under[idx] -= lr[idx]
+                            over = under.copy()
+                            over[idx] += 2 * lr[idx]
+                            for tag, cand in (('u', under), ('o', over)):
+                                if limits[idx][0] <= cand[idx] <= limits[idx][1]:
+                                    index[(level, k, tag)] = len(rows)
+                                    rows.append(cand)
+                            if level + 1 < len(group):
+                                up, down = state.copy(), state.copy()
+                                up[idx] += lr[idx]
+                                down[idx] -= lr[idx]
+                                nxt += [up, down, state]
+                        frontier = nxt
+                    errs = self._errors(n, np.array(rows)) if rows else []
+                    k = 0
+                    for level, idx in enumerate(group):
+                        under_err = errs[index[(level, k, 'u')]] if (level, k, 'u') in index else np.inf
+                        over_err = errs[index[(level, k, 'o')]] if (level, k, 'o') in index else np.inf
+                        if over_err < under_err:                    # ties and NaN: stay (predict.py:212-215)
+                            angles[idx] += lr[idx]
+                            k = 3 * k
+                        elif over_err > under_err:
+                            angles[idx] -= lr[idx]
+                            k = 3 * k + 1
+                        else:
+                            k = 3 * k + 2
 
                 history[1:] = history[:-1]
                 history[0] = angles
