@@ -353,7 +353,6 @@ class Predictor:
 
     def _stage_sflip(self, stage, angles, limits):
         n = stage.to_render
-        base_err = self._errors(n, angles)[0]
         temp = angles.copy()
         cam = self.camera_pose
         a = cam[5] * np.abs(np.cos(cam[3])) + cam[4] * np.abs(np.sin(cam[3]))     # predict.py:245
@@ -361,8 +360,18 @@ class Predictor:
         limit_thresh = 0.15
         close_to_limits = limit_thresh > abs(limits[0, 0] - temp[0]) or limit_thresh > abs(limits[0, 1] - temp[0])
         in_limits = limits[0, 0] <= temp[0] <= limits[0, 1]
+        # every pose this stage can ask for is known before the first answer: one batch of up to three rows
+        rows = [angles.copy()]
         if in_limits:
-            err = self._errors(n, temp)[0]
+            rows.append(temp.copy())
+        if not in_limits or close_to_limits:
+            endpoint = temp.copy()
+            endpoint[0] = limits[0][1]
+            rows.append(endpoint)
+        errs = self._errors(n, np.array(rows))
+        base_err = errs[0]
+        if in_limits:
+            err = errs[1]
             if err < base_err:
                 angles = temp                                       # alias, as predict.py:261
                 base_err = err
@@ -371,7 +380,7 @@ class Predictor:
             # the loop, so only the upper limit's error is ever used — and when the flip above was
             # accepted, `angles` IS `temp`, so angles[0] becomes the upper limit regardless.
             temp[0] = limits[0][1]
-            err = self._errors(n, temp)[0]
+            err = errs[-1]
             if err < base_err:
                 angles = temp
                 base_err = err
@@ -388,10 +397,14 @@ class Predictor:
 
     def _stage_isweep(self, stage, angles, history, err_history, limits):
         n, div = stage.to_render, stage.divs
-        base_err = self._errors(n, angles)[0]                       # not refreshed between joints (predict.py:288-289)
+        base_err = None                                             # not refreshed between joints (predict.py:288-289)
         for idx in np.where(stage.joints)[0]:
             lo, hi, space = self._sweep_space(stage, angles, idx, limits)
-            space_err = self._errors(n, space)
+            if base_err is None:                                    # the base pose rides along with the first sweep
+                space_err = self._errors(n, np.vstack([angles[None], space]))
+                base_err = space_err.pop(0)
+            else:
+                space_err = self._errors(n, space)
             x = np.linspace(lo[idx], hi[idx], div * 5)
             with np.errstate(all='ignore'):
                 predicted = cubic_interp(space[:, idx], np.array(space_err), x)
