@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +68,8 @@ struct rope_ctx {
     // small batches: per-candidate tiles in global memory that split workgroups merge into
     uint32_t *d_gtile = nullptr;
     size_t gtile_cap = 0;
+    bool gtile_dirty = true;
+    int split_target = 6144, split_cap = 32;   // workgroups aimed at per launch / most workgroups per (tile, candidate)
 
     // stored lookup table (cropped sqrt-depth of a pose grid)
     float *d_table = nullptr;
@@ -127,6 +130,8 @@ extern "C" int rope_create(rope_ctx **out, int device)
     rope_ctx *c = new (std::nothrow) rope_ctx();
     if (!c) return ROPE_E_NOMEM;
     c->device = device;
+    if (const char *e = std::getenv("ROPE_SPLIT_TARGET")) c->split_target = std::max(1, std::atoi(e));     // tuning aid
+    if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete c;
@@ -428,7 +433,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     // so the meshlets of each tile are split over several workgroups that merge into a tile in global memory.
     int split = 1;
     if (!layers && !(fp.debug & 1024)) {
-        split = std::min(16, 768 / std::max(1, c->C * c->n_tiles));
+        split = std::min(c->split_cap, c->split_target / std::max(1, c->C * c->n_tiles));
         if (split < 2) split = 1;
     }
     if (split > 1) {
@@ -437,13 +442,16 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, realloc_dev(&c->d_gtile, need));
             c->gtile_cap = need;
+            c->gtile_dirty = true;
         }
-        HIP_TRY(c, hipMemsetAsync(c->d_gtile, 0xFF, need * sizeof(uint32_t), c->stream));
+        // the scoring kernel hands the buffer back "empty"; clear it only when new, after a failed pass, or when a
+        // profiling flag may have skipped that kernel's work
+        if (c->gtile_dirty || fp.debug) HIP_TRY(c, hipMemsetAsync(c->d_gtile, 0xFF, c->gtile_cap * sizeof(uint32_t), c->stream));
+        c->gtile_dirty = true;
         RasterArgs sa = a;
         sa.split = split; sa.gtile = c->d_gtile;
         HIP_TRY(c, launch_raster(MODE_SPLIT, loss, c->C, c->stream, fp, c->rp, sa));
-        a.l_begin = a.l_end = n_render;            // nothing left to rasterise in the scoring launch
-        a.from_gtile = 1; a.gtile = c->d_gtile;
+        a.gtile = c->d_gtile;
     }
     if (layers) {
         RasterArgs la = a;
@@ -455,7 +463,14 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss & 3]; a.sums = c->d_sums;
     if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->d_frame_of; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-    HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
+    if (split > 1) {
+        int slices = 1;
+        while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->split_target) slices *= 2;
+        HIP_TRY(c, launch_score_gtile(loss, c->C, slices, c->stream, fp, a));
+        c->gtile_dirty = (fp.debug != 0);
+    } else {
+        HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
+    }
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
     HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err));

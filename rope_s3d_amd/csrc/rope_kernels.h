@@ -90,9 +90,9 @@ struct RasterArgs {
     uint64_t *sums; uint32_t *key_out; uint8_t *cover;
     float *table;                         // MODE_TABLE: C x crop_h x crop_w sqrt-depth (crop = fp.r0..c1)
     // few candidates: the meshlets of a (tile, candidate) are split over `split` workgroups (grid z) that merge
-    // their LDS tiles into gtile with atomicMin (MODE_SPLIT); a MODE_SCORE launch with from_gtile then scores it
-    int split, from_gtile;
-    uint32_t *gtile;                      // C x n_tiles x (TILE_W*TILE_H) keys, cleared to 0xFFFFFFFF
+    // their LDS tiles into gtile with atomicMin (MODE_SPLIT); score_gtile_kernel then scores and re-clears it
+    int split;
+    uint32_t *gtile;                      // C x n_tiles x (TILE_W*TILE_H) keys, 0xFFFFFFFF between passes
 };
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
@@ -103,6 +103,8 @@ hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const Rob
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                          const RasterArgs &a);
+// scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)
+hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a);
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,
                         uint64_t *empty_sums, uint64_t *total);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,

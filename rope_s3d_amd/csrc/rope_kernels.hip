@@ -518,6 +518,7 @@ __device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
 }
 
 static_assert(TILE_W <= 256 && TILE_H <= 256, "row-pass items carry tile coordinates in 8 bits");
+static_assert(TILE_H % 8 == 0 && TILE_W % 4 == 0, "score_gtile_kernel slices a tile into up to 8 row bands of 16-byte groups");
 
 // Samples of row v covered by the half-space: narrows [lo,hi].  One code path for both signs of A (the lanes of
 // a wave hold edges of every orientation): A > 0: u >= ceil(n/A) = floor((n+A-1)/A);  A < 0: u <= floor(-n/-A).
@@ -587,13 +588,10 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     const uint32_t *layer_tile = nullptr;
     if (MODE != MODE_LAYER && ra.layer_of && hit_lo)
         layer_tile = ra.layers + ((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
-    // MODE_SCORE after a MODE_SPLIT launch: the whole tile was rasterised already and sits in global memory
-    const bool from_gtile = (MODE == MODE_SCORE) && ra.from_gtile;
-    if (from_gtile) layer_tile = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
 
     // A candidate whose own links cannot touch this tile (mask_hi comes from the very boxes the list below is built
     // from) keeps its layer's sums: no list, no tile, no barrier.
-    if (MODE == MODE_SCORE && layer_tile && !from_gtile && !hit_hi) {
+    if (MODE == MODE_SCORE && layer_tile && !hit_hi) {
         if (tid < ROPE_SUM_WORDS) {
             const uint64_t d = ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
             if (d) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)d);
@@ -607,14 +605,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     // --- tile initialisation (a copy of the layer tile, or "empty"), link matrices, and the list of meshlets whose
     // screen box meets this tile: all in one phase so that the global loads overlap
     if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
-    if (from_gtile) {
-        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
-            reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(layer_tile)[i];
-    } else {
-        // the shared layer is not copied in: depth testing is a minimum, so it is merged where the tile is consumed
-        for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
-            reinterpret_cast<uint4 *>(tile)[i] = make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
-    }
+    // the shared layer is not copied in: depth testing is a minimum, so it is merged where the tile is consumed
+    for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
+        reinterpret_cast<uint4 *>(tile)[i] = make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
     {
         const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
         const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
@@ -632,7 +625,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __syncthreads();
     const int n_list = s_count;
     const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1};
-    if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile) && !from_gtile) {
+    if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile)) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
         if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
             const uint64_t d = ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
@@ -907,13 +900,46 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         return;
     }
     if (fp.debug & 16) return;
-    score_tile<LOSS, true>(tile, from_gtile ? nullptr : layer_tile, row0, col0, fp, n_render, tq, t32, tl, lds_sums, rc);
+    score_tile<LOSS, true>(tile, layer_tile, row0, col0, fp, n_render, tq, t32, tl, lds_sums, rc);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
         uint64_t delta = lds_sums[tid];
-        if (layer_tile && !from_gtile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
+        if (layer_tile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
         if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
     }
+}
+
+// Small batches, second half: MODE_SPLIT left every (candidate, tile) image merged in global memory.  Grid =
+// (tiles, candidates, row slices): a workgroup scores its slice of rows straight from there (delta against
+// "nothing rendered"), adds the sums to the candidate's, and puts the slice back to "empty" — the buffer is clean
+// again when the pass ends, so no clearing launch is needed before the next one.
+template <int LOSS>
+__global__ void __launch_bounds__(256)
+score_gtile_kernel(FrameParams fp, RasterArgs ra)
+{
+    __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
+    const int tid = threadIdx.x, tile_id = blockIdx.x, cand = blockIdx.y;
+    const size_t mw = (size_t)cand * ra.mask_words + (tile_id >> 5);
+    if (!(((ra.mask_lo[mw] | ra.mask_hi[mw]) >> (tile_id & 31)) & 1u)) return;      // MODE_SPLIT left this tile alone
+    const size_t frame = ra.frame_of ? (size_t)ra.frame_of[cand] : 0, plane = (size_t)fp.W * fp.H;
+    const uint64_t *__restrict__ tq = ra.tq ? ra.tq + frame * plane : nullptr;
+    const float *__restrict__ t32 = ra.t32 ? ra.t32 + frame * plane : nullptr;
+    const uint64_t *__restrict__ tl = ra.tl ? ra.tl + frame * plane * ROPE_MAX_LINKS : nullptr;
+    if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
+    __syncthreads();
+    const int rows = TILE_H / (int)gridDim.z;
+    const TileRect rc = {(int)blockIdx.z * rows, (int)blockIdx.z * rows + rows - 1, 0, TILE_W / 4 - 1};
+    uint32_t *g = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
+    const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
+    if (!(fp.debug & 16)) score_tile<LOSS, true>(g, nullptr, ty * TILE_H, tx * TILE_W, fp, ra.n_render, tq, t32, tl, lds_sums, rc);
+    __syncthreads();
+    uint4 *g4 = reinterpret_cast<uint4 *>(g) + rc.r_lo * (TILE_W / 4);
+    for (int i = tid; i < rows * (TILE_W / 4); i += blockDim.x) {
+        const uint4 k = g4[i];
+        if ((k.x & k.y & k.z & k.w) != KEY_EMPTY) g4[i] = make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
+    }
+    if (tid < ROPE_SUM_WORDS && lds_sums[tid])
+        atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)lds_sums[tid]);
 }
 
 // ------------------------------------------------------------- lookup table -----
@@ -1108,6 +1134,19 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
     else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a);
     else if (loss == ROPE_LOSS_CAMFULL) launch_one<ROPE_LOSS_CAMFULL, MODE_SCORE>(grid, st, fp, rp, a);
     else launch_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a)
+{
+    dim3 grid(fp.tiles_x * fp.tiles_y, rows, slices);
+    switch (loss) {
+    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(score_gtile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(256), 0, st, fp, a); break;
+    case ROPE_LOSS_FULL: hipLaunchKernelGGL(score_gtile_kernel<ROPE_LOSS_FULL>, grid, dim3(256), 0, st, fp, a); break;
+    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(score_gtile_kernel<ROPE_LOSS_LOOKUP>, grid, dim3(256), 0, st, fp, a); break;
+    case ROPE_LOSS_CAMFULL: hipLaunchKernelGGL(score_gtile_kernel<ROPE_LOSS_CAMFULL>, grid, dim3(256), 0, st, fp, a); break;
+    default: hipLaunchKernelGGL(score_gtile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(256), 0, st, fp, a); break;
+    }
     return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ bits = np.zeros(ids.shape, np.uint64)
 for l in range(6):
     bits |= (ids == l).astype(np.uint64) << np.uint64(l)
 e.set_target(eng.pack_target(depth.astype(np.float64), bits), depth, np.array([3] * 6 + [0, 0], np.uint8))
-for C in (2, 8, 26, 64, 256):
+for C in ([int(c) for c in sys.argv[3].split(',')] if len(sys.argv) > 3 else (2, 8, 26, 64, 256)):
     cand = q + rng.uniform(-.05, .05, (C, 6)) * np.array([1, 1, 1, 0, 0, 0])
     e.eval(cand, 6, eng.LOSS_FULL)
     t0 = time.perf_counter()
