@@ -64,9 +64,14 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample):
     t0 = time.perf_counter()
     o.eval(sample, orc.LOSS_DEPTH, 6, tq, threads=threads)
     dt = time.perf_counter() - t0
+    one = sample[:max(threads * 4, 64)]
+    t1 = time.perf_counter()
+    o.eval(one, orc.LOSS_DEPTH, 6, tq, threads=1)
+    dt1 = time.perf_counter() - t1
     return {"value": len(sample) / dt, "unit": "poses/s", "cores": threads, "kind": "port",
+            "single_thread_value": len(one) / dt1,
             "sample": f"first {len(sample)} of the {len(cand)} grid candidates, {threads} threads over candidates, "
-                      f"{dt:.2f} s wall"}
+                      f"{dt:.2f} s wall; single thread: first {len(one)} candidates, {dt1:.2f} s"}
 
 
 def main():
@@ -185,7 +190,7 @@ def main():
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
                                               "pass_total": kern['total']}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C))
         print(json.dumps(out))
     if world > 1:

@@ -20,15 +20,18 @@ def resize_linear(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
         # strided views below are exactly the gathers of the general path (same operations, same order)
         f = W // out_w
         a, b = f // 2 - 1, f // 2
+        # gather the four taps first, convert after: only 4/f^2 of the frame is ever touched
+        taa, tab, tba, tbb = img[a::f, a::f], img[a::f, b::f], img[b::f, a::f], img[b::f, b::f]
         if img.dtype == np.uint8:
-            s = img.astype(np.int64)
-            r0 = (s[a::f, a::f] * 1024 + s[a::f, b::f] * 1024) >> 4
-            r1 = (s[b::f, a::f] * 1024 + s[b::f, b::f] * 1024) >> 4
+            taa, tab, tba, tbb = (t.astype(np.int64) for t in (taa, tab, tba, tbb))
+            r0 = (taa * 1024 + tab * 1024) >> 4
+            r1 = (tba * 1024 + tbb * 1024) >> 4
             return np.clip((((1024 * r0) >> 16) + ((1024 * r1) >> 16) + 2) >> 2, 0, 255).astype(np.uint8)
-        work = img.astype(np.float64 if img.dtype == np.float64 else np.float32)
-        h = work.dtype.type(0.5)
-        top = work[a::f, a::f] * h + work[a::f, b::f] * h
-        bot = work[b::f, a::f] * h + work[b::f, b::f] * h
+        wt = np.float64 if img.dtype == np.float64 else np.float32
+        taa, tab, tba, tbb = (t.astype(wt) for t in (taa, tab, tba, tbb))
+        h = wt(0.5)
+        top = taa * h + tab * h
+        bot = tba * h + tbb * h
         return (top * h + bot * h).astype(img.dtype)
 
     def taps(n_out, n_in):
