@@ -320,6 +320,12 @@ __global__ void total_tiles_kernel(const uint64_t *__restrict__ empty_sums, int 
 }
 
 // ------------------------------------------------------------------ raster -----
+// number of set bits of `m` below this lane (v_mbcnt: no lane-mask registers to keep alive)
+__device__ static inline int bits_below_lane(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 struct SVert { int32_t X, Y; float d; };
 #define SV_BAD INT32_MIN
 
@@ -730,7 +736,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             }
             const int total = __shfl(incl, 63, 64);
             const int excl = incl - rows;
-            const int qpos = __popcll(qmask & ((1ull << lane) - 1));
+            const int qpos = bits_below_lane(qmask);
             const int nchunks = (total + 63) >> 6;
             for (int i = lane; i < nchunks; i += 64) wmask[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -748,7 +754,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 const int base = chunk << 6, item = base + lane;
                 const int before = __popcll(__ballot(rows > 0 && excl < base));   // triangles that start in earlier chunks
                 const unsigned long long mk = wmask[chunk];
-                const int slot = max(min(before + __popcll(mk & ((2ull << lane) - 1ull)) - 1, qn - 1), 0);
+                const int slot = max(min(before + bits_below_lane(mk) + (int)((mk >> lane) & 1ull) - 1, qn - 1), 0);
                 const int so = woff[slot];
                 const int src = so >> 16;                      // owner lane: its registers hold the set-up
                 // every lane takes part in the exchanges (inactive source lanes would read as garbage)
@@ -804,12 +810,15 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         // ---- pass 1: cull.  Keep front-facing triangles whose bounding box holds a sample of this tile and
         // compact them, so that the expensive set-up below runs on full lanes (about one triangle in four survives).
         int ns = 0;
+        static_assert(MESHLET_MAX_TRIS <= 128, "the cull loop fetches its index words for two steps of 64 up front");
+        const uint32_t packed_a = lane < nt ? rp.ml_tris[t0 + lane] : 0u;              // both loads in flight together
+        const uint32_t packed_b = 64 + lane < nt ? rp.ml_tris[t0 + 64 + lane] : 0u;
         for (int tb = 0; tb < nt; tb += 64) {
             const int t = tb + lane;
             bool keep = false;
             uint32_t packed = 0;
             if (t < nt) {
-                packed = rp.ml_tris[t0 + t];
+                packed = tb == 0 ? packed_a : packed_b;
                 const SVert a = wv[packed & 0xFF], b = wv[(packed >> 8) & 0xFF], c = wv[(packed >> 16) & 0xFF];
                 if (a.X != SV_BAD && b.X != SV_BAD && c.X != SV_BAD) {
                     bool front;
@@ -823,7 +832,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 }
             }
             const unsigned long long km = __ballot(keep);
-            if (keep) wkeep[ns + __popcll(km & ((1ull << lane) - 1))] = packed;
+            if (keep) wkeep[ns + bits_below_lane(km)] = packed;
             ns += __popcll(km);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
