@@ -797,10 +797,10 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 mm[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_mvp[16 * l + k])));
-#pragma unroll 1
-            for (int v = lane; v < nv; v += 64) {
-                const float *p = rp.ml_verts + 3 * (size_t)(v0 + v);
-                wv[v] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
+            static_assert(MESHLET_MAX_VERTS <= 64, "one vertex per lane");
+            if (lane < nv) {
+                const float *p = rp.ml_verts + 3 * (size_t)(v0 + lane);
+                wv[lane] = shade_vertex(mm, p[0], p[1], p[2], hw, hh);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
