@@ -164,21 +164,20 @@ __device__ static inline void acc_sq(uint64_t *s, uint64_t dq)
 
 // Loss terms of one pixel given its z-buffer key.  `pix` indexes the H x W target planes.
 template <int LOSS, bool NEG = false>
-__device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t *__restrict__ tq,
-                                          const float *__restrict__ t32, const uint64_t *__restrict__ tl, size_t plane,
+__device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t t /* tq[pix] */,
+                                          const float ta /* t32[pix] */, const uint64_t *__restrict__ tl, size_t plane,
                                           float c_num, float c_sum, float c_dif, uint64_t *s)
 {
     const bool empty = (key == KEY_EMPTY);
     float z = empty ? 0.0f : linear_depth(key >> 8, c_num, c_sum, c_dif);
     if (LOSS == ROPE_LOSS_LOOKUP || LOSS == ROPE_LOSS_TSWEEP) {
-        float a = t32[pix];
+        float a = ta;
         if (LOSS == ROPE_LOSS_TSWEEP) a = sqrtf(a);
         float diff = fabsf(a - sqrtf(z));
         uint64_t dq = q32_of_f32(diff);
         if (dq) acc_sq<NEG>(s, dq);
         return;
     }
-    const uint64_t t = tq[pix];
     if (LOSS == ROPE_LOSS_CAMFULL) {
         // CameraPredictor._error (camera_pose_prediction.py:933-970): every difference enters as its square root;
         // per link (base_link included) mask mismatches and the mean of sqrt|T_l - D*R_l| over its non-zero entries
@@ -260,21 +259,41 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
             k4.x = min(k4.x, b4.x); k4.y = min(k4.y, b4.y); k4.z = min(k4.z, b4.z); k4.w = min(k4.w, b4.w);
             if (k4.x == b4.x && k4.y == b4.y && k4.z == b4.z && k4.w == b4.w) continue;
             const uint32_t keys[4] = {k4.x, k4.y, k4.z, k4.w}, bas[4] = {b4.x, b4.y, b4.z, b4.w};
+            const int row = row0 + (4 * i4) / TILE_W, colg = col0 + (4 * i4) % TILE_W;
+            if (row >= fp.H || colg >= fp.W) continue;
+            const size_t pixg = (size_t)row * fp.W + colg;
+            // the four samples sit side by side: fetch their target words together, one wait instead of four
+            constexpr bool USE_F = (LOSS == ROPE_LOSS_LOOKUP || LOSS == ROPE_LOSS_TSWEEP);
+            uint64_t tw[4] = {0, 0, 0, 0};
+            float tf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (colg + 3 < fp.W && !(fp.W & 3)) {
+                if (USE_F) {
+                    const float4 f = *reinterpret_cast<const float4 *>(t32 + pixg);
+                    tf[0] = f.x; tf[1] = f.y; tf[2] = f.z; tf[3] = f.w;
+                } else {
+                    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(tq + pixg), b = *reinterpret_cast<const ulonglong2 *>(tq + pixg + 2);
+                    tw[0] = a.x; tw[1] = a.y; tw[2] = b.x; tw[3] = b.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (colg + j < fp.W) { if (USE_F) tf[j] = t32[pixg + j]; else tw[j] = tq[pixg + j]; }
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (keys[j] == bas[j]) continue;
-                const int i = 4 * i4 + j, row = row0 + i / TILE_W, col = col0 + i % TILE_W;
-                if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-                const size_t pix = (size_t)row * fp.W + col;
-                score_pixel<LOSS, false>(keys[j], pix, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
-                score_pixel<LOSS, true>(bas[j], pix, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
+                if (!pixel_active(row, colg + j, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
+                score_pixel<LOSS, false>(keys[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
+                score_pixel<LOSS, true>(bas[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
             }
         }
     } else {
         for (int i = threadIdx.x; i < TILE_W * TILE_H; i += blockDim.x) {
             int row = row0 + i / TILE_W, col = col0 + i % TILE_W;
             if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-            score_pixel<LOSS>(KEY_EMPTY, (size_t)row * fp.W + col, n_render, tq, t32, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
+            const size_t pix = (size_t)row * fp.W + col;
+            constexpr bool USE_F = (LOSS == ROPE_LOSS_LOOKUP || LOSS == ROPE_LOSS_TSWEEP);
+            score_pixel<LOSS>(KEY_EMPTY, pix, n_render, USE_F ? 0ull : tq[pix], USE_F ? t32[pix] : 0.0f, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
         }
     }
     // one LDS atomic per word and wave: the partial sums (modulo 2^64) are added up across the lanes first, and
