@@ -138,10 +138,10 @@ __device__ static inline uint64_t q32_of_f32(float z)
 {
     const uint32_t b = __float_as_uint(z);
     const int ex = (int)(b >> 23) & 0xFF;
-    if (ex == 0) return 0;                                   // zero and denormals: below one unit of 2^-32
-    const uint64_t m = (uint64_t)((b & 0x7FFFFFu) | 0x800000u);
+    // zero and denormals are below one unit of 2^-32; no branches: both shifts are always executed, one of them by 0
+    const uint64_t m = ex ? (uint64_t)((b & 0x7FFFFFu) | 0x800000u) : 0ull;
     const int sh = ex - 127 - 23 + 32;                        // z = m * 2^(ex-150)
-    return sh >= 0 ? (m << sh) : (sh > -64 ? (m >> -sh) : 0);
+    return (m << min(max(sh, 0), 63)) >> min(max(-sh, 0), 63);
 }
 
 // floor(sqrt(x) * 2^32) for x given in Q32: sqrt(dq * 2^-32) * 2^32 = sqrt(dq) * 2^16; one correctly rounded
@@ -202,7 +202,8 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
     if (empty && t == 0) return;                  // nothing rendered, no target: every term is zero
     const uint64_t T = t & 0x7FFFFFFFFFull, zq = q32_of_f32(z);
     const uint64_t dq = T > zq ? T - zq : zq - T;
-    if (dq) { acc<NEG>(s[SUM_CNT], 1); acc_sq<NEG>(s, dq); }
+    acc<NEG>(s[SUM_CNT], (uint64_t)(dq != 0));    // unconditional: a zero difference adds zeros
+    acc_sq<NEG>(s, dq);
     if (LOSS == ROPE_LOSS_FULL) {
         const unsigned mask = (unsigned)(t >> 40) & 0xFFu;
         const int id = empty ? 255 : (int)(key & 0xFF);
