@@ -735,9 +735,18 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                                 }
                             }
                         } else {
-                            rows = h;
+                            // one item per row — or per column when the box is taller than wide (upright slivers of
+                            // the arm's cylinders): the half-spaces are symmetric in u and v, so the owner swaps A and B
+                            // and the items clip a vertical span instead of a horizontal one
+                            const bool tall = h > w;
+                            rows = tall ? w : h;
                             q0 = e0; q1 = e1; q2 = e2; qpl = pl;
-                            q_box = (x0 - col0) | ((x1 - col0) << 8) | ((y0 - tf.vy0) << 16) | ((int)l << 24);
+                            if (tall) {
+                                q0.A = e0.B; q0.B = e0.A; q1.A = e1.B; q1.B = e1.A; q2.A = e2.B; q2.B = e2.A;
+                                q_box = (y0 - tf.vy0) | ((y1 - tf.vy0) << 8) | ((x0 - col0) << 16) | ((int)l << 24) | (1 << 27);
+                            } else {
+                                q_box = (x0 - col0) | ((x1 - col0) << 8) | ((y0 - tf.vy0) << 16) | ((int)l << 24);
+                            }
                             q_anchor = ((col0 - pxa) & 0xFFFF) | ((tf.vy0 - pya) << 16);
                         }
                     }
@@ -785,16 +794,22 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                 Plane pl;
                 pl.gx = __shfl(qpl.gx, src, 64); pl.gy = __shfl(qpl.gy, src, 64); pl.dc = __shfl(qpl.dc, src, 64);
                 const int box = __shfl(q_box, src, 64), anchor = __shfl(q_anchor, src, 64);
-                int ulo = box & 0xFF, uhi = (box >> 8) & 0xFF;
-                const int v0q = (box >> 16) & 0xFF, dxa = (int)(short)(anchor & 0xFFFF), dya = anchor >> 16;
-                const uint32_t lq = (uint32_t)box >> 24;
+                int lo = box & 0xFF, hi = (box >> 8) & 0xFF;         // span limits along the item's line
+                const int c0q = (box >> 16) & 0xFF, dxa = (int)(short)(anchor & 0xFFFF), dya = anchor >> 16;
+                const uint32_t lq = ((uint32_t)box >> 24) & 7u;
+                const bool tall = (box >> 27) & 1;
                 if (item < total) {
-                    const int v = v0q + (item - (so & 0xFFFF));
-                    clip_span(e0, v, ulo, uhi);
-                    clip_span(e1, v, ulo, uhi);
-                    clip_span(e2, v, ulo, uhi);
-                    const float dy = (float)(v + dya);
-                    for (int u = ulo; u <= uhi; u++) depth_test_write(tile, u, v, pl, (float)(u + dxa), dy, lq);
+                    const int c = c0q + (item - (so & 0xFFFF));          // the row (or, transposed, the column) of this item
+                    clip_span(e0, c, lo, hi);
+                    clip_span(e1, c, lo, hi);
+                    clip_span(e2, c, lo, hi);
+                    if (tall) {
+                        const float dx = (float)(c + dxa);
+                        for (int v = lo; v <= hi; v++) depth_test_write(tile, c, v, pl, dx, (float)(v + dya), lq);
+                    } else {
+                        const float dy = (float)(c + dya);
+                        for (int u = lo; u <= hi; u++) depth_test_write(tile, u, c, pl, (float)(u + dxa), dy, lq);
+                    }
                 }
             }
         }
