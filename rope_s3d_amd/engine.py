@@ -184,9 +184,16 @@ class Engine:
         65 535 rows are evaluated in several launches and merged (first index of the smallest error, NaN never wins)."""
         cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
         if len(cand) <= self.MAX_BATCH:
-            self.upload_candidates(cand)
-            self.eval_resident(n_render, loss, crop)
-            return self.download(True, want_sums)
+            # one call across the boundary: upload + enqueue + sync + download (rope_eval)
+            n = len(cand)
+            err = np.empty(n, np.float64)
+            sums = np.empty((n, SUM_WORDS), np.uint64) if want_sums else None
+            crop_a = np.ascontiguousarray(crop, np.int32) if crop is not None else None
+            bi, be = C.c_int32(), C.c_double()
+            self._check(self._lib.rope_eval(self._ctx, _p(cand), n, int(n_render), int(loss), _p(crop_a), _p(err), _p(sums),
+                                            C.byref(bi), C.byref(be)), 'rope_eval')
+            self.n_candidates = n
+            return err, sums, int(bi.value), float(be.value)
         errs, sums, best, best_err = [], [], -1, np.nan
         for lo in range(0, len(cand), self.MAX_BATCH):
             e, s, bi, be = self.eval(cand[lo:lo + self.MAX_BATCH], n_render, loss, crop, want_sums)
