@@ -1,0 +1,29 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from rope_s3d_amd import SyntheticPredictor
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
+from rope_s3d_amd.prediction import predict as P
+sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '1280_720_color', 8, 'SLU', noise=False, seed=1, lookup_divisions=25)
+p = sp.predictor
+lim = sp.urdf_reader.joint_limits
+poses = [np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]) for f in range(50)]
+frames = []
+for q in poses:
+    sp.renderer.setJointAngles(q); frames.append(sp.renderer.render())
+acc = {}
+def wrap(obj, name):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t = time.perf_counter(); r = f(*a, **k); acc[name] = acc.get(name, 0) + time.perf_counter() - t; acc[name+'_n'] = acc.get(name+'_n', 0) + 1; return r
+    setattr(obj, name, g)
+for n in ('_loadSynthetic', '_stage_lookup', '_stage_descent', '_stage_sflip', '_stage_isweep', '_errors', '_downsample', '_upload_target'):
+    wrap(p, n)
+p.run(*frames[0])
+acc.clear()
+t0 = time.perf_counter()
+for c, d in frames: p.run(c, d)
+tot = time.perf_counter() - t0
+print(f"total {tot/50*1e3:.2f} ms/frame")
+for k in sorted(acc):
+    if not k.endswith('_n'): print(f"{k:18s} {acc[k]/50*1e3:7.3f} ms/frame  calls/frame {acc[k+'_n']/50:.1f}")
