@@ -35,7 +35,16 @@ def run(args):
 
     ds = Dataset(args.dataset)
     kwargs = {}
-    if ds.attrs.get('synthetic'):
+    if getattr(args, 'segmenter', None) == 'maskrcnn':
+        # BASELINE configs[2]: the segmentation stage on PyTorch-ROCm in front of the engine (predict.py:94-98,416).
+        # No trained weights exist offline: without -weights the network is random and only the plumbing and the
+        # timing are meaningful.
+        import torch
+        from rope_s3d_amd.maskrcnn import MaskRCNNSegmenter
+        sd = torch.load(args.weights, map_location='cpu') if getattr(args, 'weights', None) else None
+        kwargs['segmenter'] = MaskRCNNSegmenter(7, device=f'cuda:{gpu}', state_dict=sd,
+                                                min_confidence=0.7 if sd is not None else 0.0)
+    elif ds.attrs.get('synthetic'):
         kwargs['color_dict'] = ds.attrs['color_dict']         # link masks are read from the colour render
     am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
                    do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
@@ -66,4 +75,7 @@ if __name__ == "__main__":
     parser.add_argument('dataset', type=str, help="The dataset to predict on.")
     parser.add_argument('-angs', type=str, default='SLU', help="The joints to predict.")
     parser.add_argument('-ds_factor', type=int, default=8, help="Downsampling factor (the reference hard-codes 8).")
+    parser.add_argument('-segmenter', type=str, default=None, choices=[None, 'maskrcnn'],
+                        help="'maskrcnn': segment every frame with the Mask R-CNN stage instead of reading a synthetic set's colours.")
+    parser.add_argument('-weights', type=str, default=None, help="state_dict file for -segmenter maskrcnn (random weights otherwise).")
     run(parser.parse_args())

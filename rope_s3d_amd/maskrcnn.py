@@ -107,8 +107,19 @@ class _RPN(nn.Module):
         return logits.float().softmax(-1)[..., 1], deltas.float()
 
 
+_anchor_cache = {}
+
+
 def _pyramid_anchors(size: int, device) -> torch.Tensor:
-    """Matterport utils.generate_pyramid_anchors (anchor stride 1), normalised to [0,1] as norm_boxes does."""
+    """Matterport utils.generate_pyramid_anchors (anchor stride 1), normalised to [0,1] as norm_boxes does.
+    A function of the input size alone: built once per (size, device)."""
+    key = (size, str(device))
+    if key not in _anchor_cache:
+        _anchor_cache[key] = _build_pyramid_anchors(size, device)
+    return _anchor_cache[key]
+
+
+def _build_pyramid_anchors(size: int, device) -> torch.Tensor:
     out = []
     for scale, stride in zip(RPN_ANCHOR_SCALES, BACKBONE_STRIDES):
         n = int(math.ceil(size / stride))
@@ -134,24 +145,26 @@ def _apply_deltas(boxes, deltas):
 
 def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int) -> torch.Tensor:
     """Greedy non-maximum suppression (tf.image.non_max_suppression): indices kept, best first.
-    The pairwise IoU matrix is one GPU op; the inherently serial sweep runs over it on the host."""
+
+    The greedy rule "box j stays unless an earlier box that stays overlaps it" has exactly one solution; instead of
+    sweeping the boxes one by one it is iterated as a whole on the device — keep <- not any(earlier & keep & overlap) —
+    until nothing changes.  After t rounds at least the first t boxes are final, in practice a dozen rounds settle
+    thousands of boxes: no pairwise matrix leaves the GPU and nothing runs per box on the host."""
     if boxes.numel() == 0:
         return torch.zeros(0, dtype=torch.long, device=boxes.device)
-    order = scores.argsort(descending=True)
-    b = boxes[order]
+    order = scores.argsort(descending=True, stable=True)
+    b = boxes[order].float()
     area = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
     tl, br = torch.max(b[:, None, :2], b[None, :, :2]), torch.min(b[:, None, 2:], b[None, :, 2:])
     inter = (br - tl).clamp(min=0).prod(-1)
-    sup = ((inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-12)) > thr).cpu().numpy()   # 1 byte per pair
-    alive = np.ones(len(b), bool)
-    keep = []
-    for i in range(len(b)):
-        if alive[i]:
-            keep.append(i)
-            if len(keep) >= limit:
-                break
-            alive &= ~sup[i]
-    return order[torch.as_tensor(keep, dtype=torch.long, device=boxes.device)]
+    sup = ((inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-12)) > thr).triu_(1)   # [i, j]: earlier i suppresses j
+    keep = torch.ones(len(b), dtype=torch.bool, device=b.device)
+    for _ in range(len(b)):
+        new = ~(sup & keep[:, None]).any(0)
+        if torch.equal(new, keep):
+            break
+        keep = new
+    return order[keep.nonzero().squeeze(1)[:limit]]
 
 
 def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: int) -> torch.Tensor:
@@ -274,19 +287,28 @@ class MaskRCNN(nn.Module):
         # un-mould: boxes back to original image pixels, masks resized into their box (utils.unmold_mask)
         px = det_boxes * (self.size - 1) + torch.tensor([0, 0, 1, 1], device=dev)
         px = ((px - torch.tensor([top, left, top, left], device=dev)) / scale).round().long()
-        masks = torch.zeros((H, W, len(keep)), dtype=torch.bool, device=dev)
-        for i in range(len(keep)):
-            y1, x1, y2, x2 = [int(v) for v in px[i]]
-            y1, x1, y2, x2 = max(y1, 0), max(x1, 0), min(y2, H), min(x2, W)
-            if y2 <= y1 or x2 <= x1:
-                continue
-            mm = F.interpolate(m[i][None, None], (y2 - y1, x2 - x1), mode='bilinear', align_corners=False)[0, 0]
-            masks[y1:y2, x1:x2, i] = mm >= 0.5
+        # every detection's 28x28 mask is resized into its (clipped) box — all of them in one sampling pass over the
+        # image grid: pixel centre (Y+0.5, X+0.5) of box [y1,y2)x[x1,x2) looks up the mask at ((Y+0.5-y1)/(y2-y1), ...),
+        # which is the bilinear resize with half-pixel centres and edge clamping that the per-box resize computes
+        y1, x1 = px[:, 0].clamp(min=0), px[:, 1].clamp(min=0)
+        y2, x2 = px[:, 2].clamp(max=H), px[:, 3].clamp(max=W)
+        Y = torch.arange(H, device=dev, dtype=torch.float32)[None, :, None] + 0.5
+        X = torch.arange(W, device=dev, dtype=torch.float32)[None, None, :] + 0.5
+        hh, ww = (y2 - y1).clamp(min=1).float()[:, None, None], (x2 - x1).clamp(min=1).float()[:, None, None]
+        gy = 2 * (Y - y1.float()[:, None, None]) / hh - 1
+        gx = 2 * (X - x1.float()[:, None, None]) / ww - 1
+        grid = torch.stack([gx.expand(-1, H, W), gy.expand(-1, H, W)], -1)
+        val = F.grid_sample(m[:, None], grid, mode='bilinear', padding_mode='border', align_corners=False)[:, 0]
+        inside = (Y > y1[:, None, None]) & (Y < y2[:, None, None]) & (X > x1[:, None, None]) & (X < x2[:, None, None])
+        masks = ((val >= 0.5) & inside).permute(1, 2, 0).contiguous()
         return det_cls.cpu(), det_score.cpu(), masks.cpu()
 
 
 class MaskRCNNSegmenter:
-    """`segmenter=` adapter: colour frame (H,W,3 uint8, BGR as the dataset stores it) -> PixelLib-style result dict."""
+    """`segmenter=` adapter: colour frame (H,W,3 uint8, BGR as the dataset stores it) -> PixelLib-style result dict.
+
+    Create it (or call torch.cuda.init()) BEFORE the first Engine / Predictor of the process: PyTorch ships its own
+    copy of the HIP runtime, and it cannot take the GPU once librope_hip.so has initialised the system copy."""
 
     def __init__(self, num_classes: int = 7, device: str = 'cuda:0', state_dict: dict = None, seed: int = 0,
                  min_confidence: float = 0.7):

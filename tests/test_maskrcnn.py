@@ -53,3 +53,32 @@ def test_gpu_forward_and_predictor_adapter():
     angles = p.run(color, depth.astype(np.float64))
     assert angles.shape == (6,) and np.isfinite(angles).all()
     assert (angles[:3] >= r.robot.joint_limits[:3, 0] - 1e-9).all() and (angles[:3] <= r.robot.joint_limits[:3, 1] + 1e-9).all()
+
+
+def test_device_nms_equals_the_one_by_one_sweep():
+    """The fixed-point iteration of _nms against the textbook greedy sweep (tf.image.non_max_suppression's rule)."""
+    from rope_s3d_amd.maskrcnn import _nms
+
+    def greedy(boxes, scores, thr, limit):
+        order = np.argsort(-scores, kind='stable')
+        b = boxes[order]
+        area = np.clip(b[:, 2] - b[:, 0], 0, None) * np.clip(b[:, 3] - b[:, 1], 0, None)
+        keep, alive = [], np.ones(len(b), bool)
+        for i in range(len(b)):
+            if not alive[i]:
+                continue
+            keep.append(i)
+            if len(keep) >= limit:
+                break
+            inter = np.clip(np.minimum(b[i, 2:], b[:, 2:]) - np.maximum(b[i, :2], b[:, :2]), 0, None).prod(-1)
+            alive &= ~(inter / np.clip(area[i] + area - inter, 1e-12, None) > thr)
+        return order[keep]
+
+    rng = np.random.default_rng(0)
+    for n, thr, limit in ((1500, 0.7, 300), (400, 0.3, 100), (40, 0.5, 1000), (1, 0.5, 10)):
+        c = rng.random((n, 2)).astype(np.float32)
+        wh = (rng.random((n, 2)) * 0.2 + 0.02).astype(np.float32)
+        boxes, scores = np.concatenate([c - wh / 2, c + wh / 2], 1), rng.random(n).astype(np.float32)
+        got = _nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr, limit).numpy()
+        assert np.array_equal(got, greedy(boxes, scores, thr, limit))
+    assert len(_nms(torch.zeros((0, 4)), torch.zeros(0), 0.5, 10)) == 0
