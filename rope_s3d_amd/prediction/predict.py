@@ -184,17 +184,18 @@ class Predictor:
         (predict.py:397-413) becomes one packed plane + per-link flags in HBM."""
         self._tgt_depth = tgt_depth
         self._lookup_depth_f32 = np.ascontiguousarray(lookup_depth, dtype=np.float32)
-        self._masked_targets, self._target_masks = {}, {}
-        bits = np.zeros(tgt_depth.shape, np.uint64)
+        self._target_masks = {}
+        bits = np.zeros(tgt_depth.shape, np.uint8)
         flags = np.zeros(8, np.uint8)
+        has_depth = tgt_depth != 0
         for l, link in enumerate(self.link_names):
             if link in masks:
                 m = np.asarray(masks[link], dtype=bool)
-                tm = m * tgt_depth
-                self._masked_targets[link], self._target_masks[link] = tm, m
-                bits |= m.astype(np.uint64) << np.uint64(l)
+                self._target_masks[link] = m
+                bits |= m.view(np.uint8) << np.uint8(l)
                 flags[l] |= 1
-                if np.sum(tm != 0) > (.05 * np.sum(m)):          # predict.py:495, a target-only fact
+                # predict.py:495: np.sum(mask * depth != 0) > .05 * np.sum(mask), a target-only fact (counted, not multiplied)
+                if np.count_nonzero(m & has_depth) > (.05 * np.count_nonzero(m)):
                     flags[l] |= 2
         self._tq = pack_target(tgt_depth, bits)
         self._flags = flags
@@ -216,15 +217,15 @@ class Predictor:
         """Synthetic path: link masks are read off channel 0 of the colour render (predict.py:445-469)."""
         target_color = self._downsample(target_color, self.ds_factor)
         blue = target_color[..., 0]
-        new = np.zeros(target_depth.shape)
+        hit = np.zeros(target_depth.shape, bool)            # the reference sums the comparisons and casts to bool (predict.py:449-454)
         for k in self.color_dict:
             if k in self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED]:
-                new += blue == self.color_dict[k][0]
-        lookup_depth = target_depth * new.astype(bool).astype(float)
+                hit |= blue == self.color_dict[k][0]
+        lookup_depth = target_depth * hit
         masks = {}
         for link in self.link_names:
             m = blue == self.color_dict[link][0]
-            if np.sum(m.astype(float)) > 0:
+            if m.any():                                        # np.sum(mask) > 0 (predict.py:465)
                 masks[link] = m
         self._upload_target(target_depth, lookup_depth, masks)
         return target_depth

@@ -4,7 +4,10 @@ import numpy as np
 from rope_s3d_amd import SyntheticPredictor
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
 from rope_s3d_amd.prediction import predict as P
-sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '1280_720_color', 8, 'SLU', noise=False, seed=1, lookup_divisions=25)
+intr = sys.argv[1] if len(sys.argv) > 1 else '1280_720_color'
+ds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+div = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, intr, ds, 'SLU', noise=False, seed=1, lookup_divisions=div)
 p = sp.predictor
 lim = sp.urdf_reader.joint_limits
 poses = [np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]) for f in range(50)]
