@@ -231,7 +231,7 @@ __device__ static inline bool pixel_active(int row, int col, int W, int H, int r
 // all others are skipped without touching the target planes.  Arithmetic is
 // modulo 2^64, the frame total of the "nothing rendered" sums is added back by finalize_argmin_kernel.
 // Rows [r_lo, r_hi] and 4-sample column groups [g_lo, g_hi] of a tile that a launch may have drawn into.
-struct TileRect { int r_lo, r_hi, g_lo, g_hi; };
+struct TileRect { int r_lo, r_hi, g_lo, g_hi; int block_g; };   // block_g: log2 of a wave's block width in groups (3, 4 or 5)
 
 template <int LOSS, bool DELTA>
 __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *__restrict__ base /* global, or nullptr = nothing */,
@@ -247,14 +247,15 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
         // Only samples whose key differs from the base tile (the shared layer, or nothing) change the sums, and only
         // the rectangle this launch could draw into can hold any.  The z-test is a minimum over keys, so the tile
         // holds this launch's own samples and min(tile, base) is the finished image: the base is never copied to LDS.
-        const int gw = rc.g_hi - rc.g_lo + 1;
-        int sh = 0;
-        while ((1 << sh) < gw) sh++;                       // lanes per row: the next power of two (shifts, no division)
-        const int n_items = (rc.r_hi - rc.r_lo + 1) << sh;
+        // A wave takes a compact block of the tile — 2^BLOCK_G groups wide, 64 >> BLOCK_G rows high — instead of two
+        // whole rows: the robot's image is a blob, and the blocks inside it keep all their lanes busy.
+        static_assert((TILE_W / 4) == 32, "block mapping below assumes 32 four-sample groups per tile row");
+        const int bg = rc.block_g, brows = 64 >> bg, bpr_sh = 5 - bg;            // blocks per band of rows: 32 >> bg
+        const int n_items = (rc.r_hi - rc.r_lo + 1) * (TILE_W / 4);
         for (int it = threadIdx.x; it < n_items; it += blockDim.x) {
-            const int g = rc.g_lo + (it & ((1 << sh) - 1));
-            if (g > rc.g_hi) continue;
-            const int i4 = (rc.r_lo + (it >> sh)) * (TILE_W / 4) + g;
+            const int b = it >> 6, l = it & 63;
+            const int g = ((b & ((1 << bpr_sh) - 1)) << bg) | (l & ((1 << bg) - 1));
+            const int i4 = (rc.r_lo + (b >> bpr_sh) * brows + (l >> bg)) * (TILE_W / 4) + g;
             uint4 k4 = reinterpret_cast<const uint4 *>(tile)[i4];
             const uint4 b4 = base ? reinterpret_cast<const uint4 *>(base)[i4] : make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
             k4.x = min(k4.x, b4.x); k4.y = min(k4.y, b4.y); k4.z = min(k4.z, b4.z); k4.w = min(k4.w, b4.w);
@@ -325,7 +326,7 @@ empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *
     if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
     __syncthreads();
     int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, tl, lds_sums, TileRect{0, TILE_H - 1, 0, TILE_W / 4 - 1});
+    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, tl, lds_sums, TileRect{0, TILE_H - 1, 0, TILE_W / 4 - 1, 5});
     __syncthreads();
     if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
 }
@@ -650,7 +651,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     }
     __syncthreads();
     const int n_list = s_count;
-    const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1};
+    const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1, 3};          // 8 groups x 8 rows per wave (TILE_H % 8 == 0)
     if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile)) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
         if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
@@ -972,7 +973,7 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
     if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
     __syncthreads();
     const int rows = TILE_H / (int)gridDim.z;
-    const TileRect rc = {(int)blockIdx.z * rows, (int)blockIdx.z * rows + rows - 1, 0, TILE_W / 4 - 1};
+    const TileRect rc = {(int)blockIdx.z * rows, (int)blockIdx.z * rows + rows - 1, 0, TILE_W / 4 - 1, 4};   // 16 groups x 4 rows (bands are multiples of 4 rows)
     uint32_t *g = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
     const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
     if (!(fp.debug & 16)) score_tile<LOSS, true>(g, nullptr, ty * TILE_H, tx * TILE_W, fp, ra.n_render, tq, t32, tl, lds_sums, rc);
