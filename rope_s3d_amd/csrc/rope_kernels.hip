@@ -546,6 +546,7 @@ __device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
 
 static_assert(TILE_W <= 256 && TILE_H <= 256, "row-pass items carry tile coordinates in 8 bits");
 static_assert(TILE_H % 8 == 0 && TILE_W % 4 == 0, "score_gtile_kernel slices a tile into up to 8 row bands of 16-byte groups");
+static_assert(TILE_H % 16 == 0, "the loss pass of raster_score_kernel walks the tile in blocks of 16 rows");
 
 // Samples of row v covered by the half-space: narrows [lo,hi].  One code path for both signs of A (the lanes of
 // a wave hold edges of every orientation): A > 0: u >= ceil(n/A) = floor((n+A-1)/A);  A < 0: u <= floor(-n/-A).
@@ -651,7 +652,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     }
     __syncthreads();
     const int n_list = s_count;
-    const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1, 3};          // 8 groups x 8 rows per wave (TILE_H % 8 == 0)
+    const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1, 2};          // 4 groups x 16 rows per wave: measured best of 32x2, 8x8, 4x16, 2x32
     if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile)) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
         if (MODE == MODE_SCORE && layer_tile && tid < ROPE_SUM_WORDS) {
