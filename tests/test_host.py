@@ -266,3 +266,27 @@ def test_missing_library_fails_loudly(tmp_path):
         for node in ast.walk(ast.parse(f.read_text())):
             names = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ''] if isinstance(node, ast.ImportFrom) else [])
             assert not any(n == 'oracle' or n.startswith('oracle.') for n in names), f
+
+
+def test_analysis_tables_and_joint_distance(tmp_path, capsys):
+    """Grapher (degrees, B wrap-around) and JointDistance (FK distances) of prediction/analysis.py, and plot_errors.py on a
+    synthetic-run file."""
+    from rope_s3d_amd.prediction.analysis import Grapher, JointDistance
+    actual = np.zeros((4, 6))
+    pred = actual.copy()
+    pred[:, 0] += np.radians([1, 2, 3, 4])
+    pred[:, 4] += np.pi                                       # half a turn off on B: corrected away
+    st = Grapher('SB', pred, actual).plot()
+    assert np.allclose(st['mean'], [2.5, 0.0]) and np.allclose(st['max'], [4.0, 0.0])
+    jd = JointDistance()
+    d = jd.distance(pred[:, :6] * np.array([1, 0, 0, 0, 0, 0]), actual)
+    # rotating S by a moves the L frame origin (0.088 m off the S axis) along a chord of length 2 r sin(a/2); S itself stays put
+    assert np.allclose(d[:, 0], 0) and np.allclose(d[:, 1], 2 * 0.088 * np.sin(np.radians([1, 2, 3, 4]) / 2))
+    assert jd.single(pred, actual, 'T').shape == (4, 1)
+    np.save(tmp_path / 'synth_test.npy', np.stack([actual, pred]))
+    import importlib
+    pe = importlib.import_module('plot_errors')
+    import argparse
+    pe.run(argparse.Namespace(file=str(tmp_path / 'synth_test'), sort_by='S', angs='SLU', dataset=None))
+    out = capsys.readouterr().out
+    assert 'Err Stats (deg)' in out and 'Err Stats (cm)' in out

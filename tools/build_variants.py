@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.p
 from rope_s3d_amd import build
 VARIANTS = {
     'base': '',
-    'v64_h96_w12': '-DROPE_MESHLET_MAX_VERTS=64 -DROPE_TILE_H=96 -DROPE_NWAVES=12',
-    'v64_w256_w12': '-DROPE_MESHLET_MAX_VERTS=64 -DROPE_TILE_W=256 -DROPE_NWAVES=12',
-    'v64_w192_h64_w12': '-DROPE_MESHLET_MAX_VERTS=64 -DROPE_TILE_W=192 -DROPE_TILE_H=64 -DROPE_NWAVES=12',
-    'v64_w160_h72_w12': '-DROPE_MESHLET_MAX_VERTS=64 -DROPE_TILE_W=160 -DROPE_TILE_H=72 -DROPE_NWAVES=12',
+    'c2r2': '-DROPE_SMALL_TRI_COLS=2 -DROPE_SMALL_TRI_ROWS=2',
+    'c4r2': '-DROPE_SMALL_TRI_COLS=4 -DROPE_SMALL_TRI_ROWS=2',
+    'c2r4': '-DROPE_SMALL_TRI_COLS=2 -DROPE_SMALL_TRI_ROWS=4',
+    'c3r3': '-DROPE_SMALL_TRI_COLS=3 -DROPE_SMALL_TRI_ROWS=3',
+    'c6r6': '-DROPE_SMALL_TRI_COLS=6 -DROPE_SMALL_TRI_ROWS=6',
 }
 for name, flags in VARIANTS.items():
     os.environ['ROPE_HIPCC_EXTRA'] = flags
