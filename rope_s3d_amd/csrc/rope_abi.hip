@@ -417,6 +417,22 @@ static RasterArgs base_args(rope_ctx *c, int n_render)
     return a;
 }
 
+// forward kinematics + link matrices + screen boxes + tile masks (+ cleared sums) of the resident candidates
+static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const FrameParams &fp, bool views)
+{
+    const double *PV = views ? c->d_PVs : c->d_PV;
+    const int32_t *view_of = views ? c->d_view_of : nullptr;
+    if (c->C <= 256) {                              // one fused launch, one workgroup per candidate
+        HIP_TRY(c, launch_fk_bounds(c->stream, c->d_cand, c->C, fp, c->rp, n_render, n_shared, c->d_joint_fixed, c->d_joint_axes, PV,
+                                    view_of, c->d_mvp, c->d_bounds, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+        return ROPE_OK;
+    }
+    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
+                         c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    return ROPE_OK;
+}
+
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
                         hipEvent_t *ev /* 5 events or nullptr */, bool views = false)
 {
@@ -424,9 +440,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, views ? c->d_PVs : c->d_PV,
-                         views ? c->d_view_of : nullptr, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
-    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    { int rc = enqueue_geometry(c, n_render, n_shared, fp, views); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     RasterArgs a = base_args(c, n_render);
     // Few candidates (descent pairs, flips): one workgroup per (tile, candidate) would leave most of the chip idle,
@@ -530,8 +544,8 @@ static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "render: n_render out of range");
     int rc = rope_candidates_upload(c, cand, C);
     if (rc) return rc;
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, nullptr, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
-    HIP_TRY(c, launch_bounds(c->stream, c->C, c->fp, c->rp, n_render, 0, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    rc = enqueue_geometry(c, n_render, 0, c->fp, false);
+    if (rc) return rc;
     RasterArgs a = base_args(c, n_render);
     a.key_out = c->d_key; a.cover = c->d_cover;
     HIP_TRY(c, launch_raster(mode, ROPE_LOSS_DEPTH, c->C, c->stream, c->fp, c->rp, a));
@@ -598,8 +612,8 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
     const bool layers = want_layers(c);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { rc = ensure_layers(c); if (rc) return rc; }
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, c->d_PV, nullptr, c->d_mvp, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
-    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    rc = enqueue_geometry(c, n_render, n_shared, fp, false);
+    if (rc) return rc;
     RasterArgs a = base_args(c, n_render);
     if (layers) {
         // layer pass without loss sums (layer_sums == nullptr): no target is needed to build a table

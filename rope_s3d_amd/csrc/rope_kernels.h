@@ -101,6 +101,11 @@ hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, co
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
+// small batches: launch_fk + launch_bounds as one kernel, one workgroup per candidate
+hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const FrameParams &fp, const RobotParams &rp, int n_render,
+                            int n_shared, const double *joint_fixed, const double *joint_axes, const double *PV,
+                            const int32_t *view_of, float *mvp, short4 *bounds, uint64_t *sums, uint32_t *mask_lo,
+                            uint32_t *mask_hi, int mask_words);
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                          const RasterArgs &a);
 // scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)

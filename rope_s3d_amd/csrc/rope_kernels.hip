@@ -80,6 +80,29 @@ __device__ static inline void aff_mul(const double *A, const double *B, double *
     }
 }
 
+// A_j = F_j · Rot(axis_j, q_j): parent-link frame -> link j+1 frame (12 doubles, 3x4 row-major)
+__device__ static inline void joint_matrix(double q, int j, const double *__restrict__ joint_fixed, const double *__restrict__ joint_axes,
+                                           double *A)
+{
+    double s, co;
+    det_sincos(q, s, co);
+    const double t = 1.0 - co, ax = joint_axes[3 * j], ay = joint_axes[3 * j + 1], az = joint_axes[3 * j + 2];
+    double R[12], F[12];
+    R[0] = (t * ax) * ax + co;      R[1] = (t * ax) * ay - s * az;  R[2] = (t * ax) * az + s * ay;  R[3] = 0.0;
+    R[4] = (t * ax) * ay + s * az;  R[5] = (t * ay) * ay + co;      R[6] = (t * ay) * az - s * ax;  R[7] = 0.0;
+    R[8] = (t * ax) * az - s * ay;  R[9] = (t * ay) * az + s * ax;  R[10] = (t * az) * az + co;     R[11] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) F[k] = joint_fixed[12 * j + k];
+    aff_mul(F, R, A);
+}
+
+// element (r, k) of P·V·T rounded to float32 (T: 3x4 affine, last row 0 0 0 1)
+__device__ static inline float mvp_element(const double *__restrict__ PV, const double *T, int r, int k)
+{
+    const double p0 = PV[4 * r], p1 = PV[4 * r + 1], p2 = PV[4 * r + 2], p3 = PV[4 * r + 3];
+    return k < 3 ? (float)((p0 * T[0 + k] + p1 * T[4 + k]) + p2 * T[8 + k]) : (float)(((p0 * T[3] + p1 * T[7]) + p2 * T[11]) + p3);
+}
+
 // One thread per candidate.  Writes n_render 4x4 float matrices.
 __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
@@ -97,29 +120,17 @@ fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double
     double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (int l = 0; l < n_render; l++) {
         if (l > 0) {
-            int j = l - 1;
-            double s, co;
-            det_sincos(cand[6 * c + j], s, co);
-            double t = 1.0 - co, ax = joint_axes[3 * j], ay = joint_axes[3 * j + 1], az = joint_axes[3 * j + 2];
-            double R[12], A[12], N[12], F[12];
-            R[0] = (t * ax) * ax + co;      R[1] = (t * ax) * ay - s * az;  R[2] = (t * ax) * az + s * ay;  R[3] = 0.0;
-            R[4] = (t * ax) * ay + s * az;  R[5] = (t * ay) * ay + co;      R[6] = (t * ay) * az - s * ax;  R[7] = 0.0;
-            R[8] = (t * ax) * az - s * ay;  R[9] = (t * ay) * az + s * ax;  R[10] = (t * az) * az + co;     R[11] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 12; k++) F[k] = joint_fixed[12 * j + k];
-            aff_mul(F, R, A);
+            double A[12], N[12];
+            joint_matrix(cand[6 * c + l - 1], l - 1, joint_fixed, joint_axes, A);
             aff_mul(T, A, N);
 #pragma unroll
             for (int k = 0; k < 12; k++) T[k] = N[k];
         }
         float *o = mvp + ((size_t)c * ROPE_MAX_LINKS + l) * 16;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double p0 = PV[4 * r], p1 = PV[4 * r + 1], p2 = PV[4 * r + 2], p3 = PV[4 * r + 3];
+        for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) o[4 * r + k] = (float)((p0 * T[0 + k] + p1 * T[4 + k]) + p2 * T[8 + k]);
-            o[4 * r + 3] = (float)(((p0 * T[3] + p1 * T[7]) + p2 * T[11]) + p3);
-        }
+            for (int k = 0; k < 4; k++) o[4 * r + k] = mvp_element(PV, T, r, k);
     }
 }
 
@@ -383,6 +394,55 @@ __device__ static inline int64_t edge_fn(int32_t ax, int32_t ay, int32_t bx, int
 // eight corners of its link-frame box, plus per candidate a bit mask of the tiles any meshlet may touch.
 // Conservative by construction (1 px margin over rounding and sub-pixel snapping): it only ever removes
 // work that cannot produce a sample, never a sample.  Empty boxes are stored as x0 > x1.
+// box of meshlet m under the link matrices `mvp6` (6 x 16 floats); marks the tiles it may touch in s_mask (LDS)
+__device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotParams &rp, int m, int n_render, int n_shared,
+                                            const float *mvp6, uint32_t (*s_mask)[MAX_MASK_WORDS])
+{
+    short4 bb = make_short4(1, 0, 1, 0);
+    const int l = (int)rp.ml_header[8 * m + 7];
+    if (l >= n_render) return bb;
+    const float4 ctr = reinterpret_cast<const float4 *>(rp.ml_aabb)[2 * m];
+    const float4 ext = reinterpret_cast<const float4 *>(rp.ml_aabb)[2 * m + 1];
+    const float *mm = mvp6 + l * 16;
+    const float hw = 0.5f * (float)fp.W, hh = 0.5f * (float)fp.H;
+    float sxlo = 3.0e38f, sxhi = -3.0e38f, sylo = 3.0e38f, syhi = -3.0e38f;
+    bool behind = false, front = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x = ctr.x + ((k & 1) ? ext.x : -ext.x), y = ctr.y + ((k & 2) ? ext.y : -ext.y),
+                    z = ctr.z + ((k & 4) ? ext.z : -ext.z);
+        const float cx = fmaf(mm[0], x, fmaf(mm[1], y, fmaf(mm[2], z, mm[3])));
+        const float cy = fmaf(mm[4], x, fmaf(mm[5], y, fmaf(mm[6], z, mm[7])));
+        const float cw = fmaf(mm[12], x, fmaf(mm[13], y, fmaf(mm[14], z, mm[15])));
+        if (cw <= 1e-4f) { behind = true; continue; }
+        front = true;
+        const float rw = 1.0f / cw;
+        const float sx = fmaf(cx * rw, hw, hw), sy = fmaf(cy * rw, hh, hh);
+        sxlo = fminf(sxlo, sx); sxhi = fmaxf(sxhi, sx);
+        sylo = fminf(sylo, sy); syhi = fmaxf(syhi, sy);
+    }
+    if (!front) return bb;
+    int x0, x1, y0, y1;
+    if (behind) { x0 = 0; x1 = fp.W - 1; y0 = 0; y1 = fp.H - 1; }   // straddles the eye plane: cannot bound
+    else {
+        // sample centre p+0.5 inside [lo,hi] (+ margin)  <=>  p in [lo-1.5, hi+0.5]
+        x0 = (int)fmaxf(floorf(sxlo - 1.5f), 0.0f); x1 = (int)fminf(ceilf(sxhi + 0.5f), (float)(fp.W - 1));
+        y0 = (int)fmaxf(floorf(sylo - 1.5f), 0.0f); y1 = (int)fminf(ceilf(syhi + 0.5f), (float)(fp.H - 1));
+    }
+    if (x0 > x1 || y0 > y1) return bb;
+    // bit 14 of x0: the meshlet's unclamped screen extent is at most COMPACT_PX both ways
+    const bool compact = !behind && (sxhi - sxlo) <= (float)COMPACT_PX && (syhi - sylo) <= (float)COMPACT_PX;
+    bb = make_short4((short)(x0 | (compact ? 0x4000 : 0)), (short)x1, (short)y0, (short)y1);
+    const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
+    const int ty0 = (fp.H - 1 - y1) / TILE_H, ty1 = (fp.H - 1 - y0) / TILE_H;
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) {
+            const int t = ty * fp.tiles_x + tx;
+            atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
+        }
+    return bb;
+}
+
 __global__ void __launch_bounds__(256)
 bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const float *__restrict__ mvp_all,
               short4 *__restrict__ bounds, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words)
@@ -391,58 +451,58 @@ bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const 
     const int cand = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) s_mask[0][i] = s_mask[1][i] = 0;
     __syncthreads();
-    if (m < rp.n_meshlets) {
-        short4 bb = make_short4(1, 0, 1, 0);
-        const int l = (int)rp.ml_header[8 * m + 7];
-        if (l < n_render) {
-            const float4 ctr = reinterpret_cast<const float4 *>(rp.ml_aabb)[2 * m];
-            const float4 ext = reinterpret_cast<const float4 *>(rp.ml_aabb)[2 * m + 1];
-            const float *mm = mvp_all + ((size_t)cand * ROPE_MAX_LINKS + l) * 16;
-            const float hw = 0.5f * (float)fp.W, hh = 0.5f * (float)fp.H;
-            float sxlo = 3.0e38f, sxhi = -3.0e38f, sylo = 3.0e38f, syhi = -3.0e38f;
-            bool behind = false, front = false;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float x = ctr.x + ((k & 1) ? ext.x : -ext.x), y = ctr.y + ((k & 2) ? ext.y : -ext.y),
-                            z = ctr.z + ((k & 4) ? ext.z : -ext.z);
-                const float cx = fmaf(mm[0], x, fmaf(mm[1], y, fmaf(mm[2], z, mm[3])));
-                const float cy = fmaf(mm[4], x, fmaf(mm[5], y, fmaf(mm[6], z, mm[7])));
-                const float cw = fmaf(mm[12], x, fmaf(mm[13], y, fmaf(mm[14], z, mm[15])));
-                if (cw <= 1e-4f) { behind = true; continue; }
-                front = true;
-                const float rw = 1.0f / cw;
-                const float sx = fmaf(cx * rw, hw, hw), sy = fmaf(cy * rw, hh, hh);
-                sxlo = fminf(sxlo, sx); sxhi = fmaxf(sxhi, sx);
-                sylo = fminf(sylo, sy); syhi = fmaxf(syhi, sy);
-            }
-            if (front) {
-                int x0, x1, y0, y1;
-                if (behind) { x0 = 0; x1 = fp.W - 1; y0 = 0; y1 = fp.H - 1; }   // straddles the eye plane: cannot bound
-                else {
-                    // sample centre p+0.5 inside [lo,hi] (+ margin)  <=>  p in [lo-1.5, hi+0.5]
-                    x0 = (int)fmaxf(floorf(sxlo - 1.5f), 0.0f); x1 = (int)fminf(ceilf(sxhi + 0.5f), (float)(fp.W - 1));
-                    y0 = (int)fmaxf(floorf(sylo - 1.5f), 0.0f); y1 = (int)fminf(ceilf(syhi + 0.5f), (float)(fp.H - 1));
-                }
-                if (x0 <= x1 && y0 <= y1) {
-                    // bit 14 of x0: the meshlet's unclamped screen extent is at most COMPACT_PX both ways
-                    const bool compact = !behind && (sxhi - sxlo) <= (float)COMPACT_PX && (syhi - sylo) <= (float)COMPACT_PX;
-                    bb = make_short4((short)(x0 | (compact ? 0x4000 : 0)), (short)x1, (short)y0, (short)y1);
-                    const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
-                    const int ty0 = (fp.H - 1 - y1) / TILE_H, ty1 = (fp.H - 1 - y0) / TILE_H;
-                    for (int ty = ty0; ty <= ty1; ty++)
-                        for (int tx = tx0; tx <= tx1; tx++) {
-                            const int t = ty * fp.tiles_x + tx;
-                            atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
-                        }
-                }
-            }
-        }
-        bounds[(size_t)cand * rp.n_meshlets + m] = bb;
-    }
+    if (m < rp.n_meshlets)
+        bounds[(size_t)cand * rp.n_meshlets + m] = meshlet_box(fp, rp, m, n_render, n_shared, mvp_all + (size_t)cand * ROPE_MAX_LINKS * 16, s_mask);
     __syncthreads();
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) {
         if (s_mask[0][i]) atomicOr(&mask_lo[(size_t)cand * mask_words + i], s_mask[0][i]);
         if (s_mask[1][i]) atomicOr(&mask_hi[(size_t)cand * mask_words + i], s_mask[1][i]);
+    }
+}
+
+// Small batches: forward kinematics and screen boxes of one candidate in ONE workgroup and one launch.  The five
+// joint matrices are built side by side, one thread chains them, 96 threads form the float32 link matrices, then
+// all 1024 walk the meshlets.  Same helper code and operation order as fk_mvp_kernel + bounds_kernel: same bits.
+__global__ void __launch_bounds__(1024)
+fk_bounds_kernel(FrameParams fp, RobotParams rp, const double *__restrict__ cand, int n_render, int n_shared,
+                 const double *__restrict__ joint_fixed, const double *__restrict__ joint_axes, const double *__restrict__ PV_all,
+                 const int32_t *__restrict__ view_of, float *__restrict__ mvp_all, short4 *__restrict__ bounds,
+                 uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words)
+{
+    __shared__ double s_A[ROPE_MAX_LINKS - 1][12], s_T[ROPE_MAX_LINKS][12];
+    __shared__ float s_m[ROPE_MAX_LINKS * 16];
+    __shared__ uint32_t s_mask[2][MAX_MASK_WORDS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const double *__restrict__ PV = PV_all + (view_of ? 16 * (size_t)view_of[c] : 0);
+    if (tid < ROPE_SUM_WORDS) sums[(size_t)c * ROPE_SUM_WORDS + tid] = 0;
+    for (int i = tid; i < mask_words; i += blockDim.x) s_mask[0][i] = s_mask[1][i] = 0;
+    if (tid < ROPE_MAX_LINKS - 1 && tid + 1 < n_render) joint_matrix(cand[6 * c + tid], tid, joint_fixed, joint_axes, s_A[tid]);
+    __syncthreads();
+    if (tid == 0) {
+        double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, N[12];
+        for (int l = 0; l < n_render; l++) {
+            if (l > 0) {
+                aff_mul(T, s_A[l - 1], N);
+#pragma unroll
+                for (int k = 0; k < 12; k++) T[k] = N[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_T[l][k] = T[k];
+        }
+    }
+    __syncthreads();
+    if (tid < n_render * 16) {
+        const float v = mvp_element(PV, s_T[tid >> 4], (tid >> 2) & 3, tid & 3);
+        s_m[tid] = v;
+        mvp_all[(size_t)c * ROPE_MAX_LINKS * 16 + tid] = v;
+    }
+    __syncthreads();
+    for (int m = tid; m < rp.n_meshlets; m += blockDim.x)
+        bounds[(size_t)c * rp.n_meshlets + m] = meshlet_box(fp, rp, m, n_render, n_shared, s_m, s_mask);
+    __syncthreads();
+    for (int i = tid; i < mask_words; i += blockDim.x) {
+        mask_lo[(size_t)c * mask_words + i] = s_mask[0][i];
+        mask_hi[(size_t)c * mask_words + i] = s_mask[1][i];
     }
 }
 
@@ -1158,6 +1218,16 @@ hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const Rob
     // the masks were cleared by fk_mvp_kernel earlier in the same pass
     hipLaunchKernelGGL(bounds_kernel, dim3((rp.n_meshlets + 255) / 256, C), dim3(256), 0, st, fp, rp, n_render, n_shared, mvp,
                        bounds, mask_lo, mask_hi, mask_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const FrameParams &fp, const RobotParams &rp, int n_render,
+                            int n_shared, const double *joint_fixed, const double *joint_axes, const double *PV,
+                            const int32_t *view_of, float *mvp, short4 *bounds, uint64_t *sums, uint32_t *mask_lo,
+                            uint32_t *mask_hi, int mask_words)
+{
+    hipLaunchKernelGGL(fk_bounds_kernel, dim3(C), dim3(1024), 0, st, fp, rp, cand, n_render, n_shared, joint_fixed, joint_axes, PV,
+                       view_of, mvp, bounds, sums, mask_lo, mask_hi, mask_words);
     return hipGetLastError();
 }
 
