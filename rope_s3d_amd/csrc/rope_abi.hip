@@ -50,6 +50,10 @@ struct rope_ctx {
     int C = 0, cap = 0;
     double *d_cand = nullptr, *d_err = nullptr, *d_best_err = nullptr;
     double *h_stage = nullptr;             // pinned staging: candidates up, errors + best down
+    // small batches: the finalize kernel writes errors + best straight into mapped pinned host memory (no copy command)
+    static constexpr int HOST_ERR_ROWS = 256;
+    double *h_err = nullptr, *d_err_host = nullptr;   // host pointer and its device alias
+    bool err_on_host = false;
     float *d_mvp = nullptr;
     short4 *d_bounds = nullptr;
     uint32_t *d_mask_lo = nullptr, *d_mask_hi = nullptr;
@@ -137,7 +141,9 @@ extern "C" int rope_create(rope_ctx **out, int device)
         delete c;
         return ROPE_E_HIP;
     }
-    if (hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
+    if (hipHostMalloc((void **)&c->h_err, (rope_ctx::HOST_ERR_ROWS + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_err_host, c->h_err, 0) != hipSuccess ||
+        hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&c->d_best_err, sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_PV, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_joint_fixed, 72 * sizeof(double)) != hipSuccess ||
@@ -162,6 +168,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -487,7 +494,9 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     }
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
-    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf, c->d_err));
+    c->err_on_host = c->C <= rope_ctx::HOST_ERR_ROWS;
+    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf,
+                               c->err_on_host ? c->d_err_host : c->d_err));
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     c->last_n_render = n_render;
     return ROPE_OK;
@@ -519,12 +528,13 @@ extern "C" int rope_results_download(rope_ctx *c, double *err_out, uint64_t *sum
     if (c->C < 1) ARG_FAIL(c, "rope_results_download: nothing evaluated");
     HIP_TRY(c, hipSetDevice(c->device));
     // one copy brings the errors, the best error and the best index (pinned staging)
-    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err, ((size_t)c->C + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const double *res = c->err_on_host ? c->h_err : c->h_stage;
+    if (!c->err_on_host) HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err, ((size_t)c->C + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (sums_out) HIP_TRY(c, hipMemcpyAsync(sums_out, c->d_sums, (size_t)c->C * ROPE_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (err_out) std::memcpy(err_out, c->h_stage, (size_t)c->C * sizeof(double));
-    if (best_err) *best_err = c->h_stage[c->C];
-    if (best_idx) *best_idx = (int32_t)c->h_stage[c->C + 1];
+    if (err_out) std::memcpy(err_out, res, (size_t)c->C * sizeof(double));
+    if (best_err) *best_err = res[c->C];
+    if (best_idx) *best_idx = (int32_t)res[c->C + 1];
     return ROPE_OK;
 }
 
