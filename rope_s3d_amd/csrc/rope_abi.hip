@@ -87,10 +87,17 @@ struct rope_ctx {
     std::vector<double> h_fq;               // n_frames x 6
     uint64_t *d_ftq = nullptr, *d_ftl = nullptr, *d_ftotal = nullptr, *d_fempty = nullptr;
     float *d_ft32 = nullptr;
-    double *d_PVs = nullptr;
-    int32_t *d_view_of = nullptr, *d_frame_of = nullptr;
-    int views_cap = 0, vf_cap = 0;
-    int ftotal_loss = -1;                   // loss the per-frame "nothing rendered" totals in d_ftotal belong to
+    // one pinned host block and its device twin per rope_eval_views call: candidates | view matrices | view index | frame index
+    unsigned char *h_vstage = nullptr, *d_vstage = nullptr;
+    size_t vstage_cap = 0;
+    const double *dv_cand = nullptr, *dv_PV = nullptr;
+    const int32_t *dv_view_of = nullptr, *dv_frame_of = nullptr;
+    uint64_t *h_vsums = nullptr;            // pinned: K x N x 23 sums, then N x 23 totals
+    unsigned char *h_copy = nullptr;        // pinned: staging of pageable host buffers on their way up (copy_h2d_staged)
+    size_t vsums_cap = 0;
+    size_t frames_cap = 0, frames_tl_cap = 0, frames_t32_cap = 0;
+    int ftotal_cap = 0;
+    bool ftotal_valid[5] = {false, false, false, false, false};   // per loss kind: d_ftotal[loss] holds the frames' "nothing rendered" totals
 
     // single-pose render scratch
     uint32_t *d_key = nullptr;
@@ -121,6 +128,10 @@ static hipError_t realloc_dev(T **p, size_t n)
 }
 
 static thread_local std::string g_create_err;
+
+// Host buffers handed over the C ABI are pageable; the runtime's own path for those is slow (measured 0.35 GB/s for
+// freshly written numpy arrays).  Go through a pinned block instead: memcpy + asynchronous copy, chunk by chunk.
+static int copy_h2d_staged(rope_ctx *c, void *dst, const void *src, size_t bytes);
 
 extern "C" int rope_create(rope_ctx **out, int device)
 {
@@ -156,6 +167,20 @@ extern "C" int rope_create(rope_ctx **out, int device)
     return ROPE_OK;
 }
 
+static int copy_h2d_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t CHUNK = 8u << 20;
+    if (!c->h_copy) HIP_TRY(c, hipHostMalloc((void **)&c->h_copy, 2 * CHUNK, hipHostMallocDefault));   // two halves, alternating
+    int half = 0;
+    for (size_t off = 0; off < bytes; off += CHUNK, half ^= 1) {
+        const size_t n = std::min(CHUNK, bytes - off);
+        if (off >= 2 * CHUNK || off == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));   // the half about to be overwritten is free again
+        std::memcpy(c->h_copy + half * CHUNK, static_cast<const unsigned char *>(src) + off, n);
+        HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, c->h_copy + half * CHUNK, n, hipMemcpyHostToDevice, c->stream));
+    }
+    return ROPE_OK;
+}
+
 extern "C" void rope_destroy(rope_ctx *c)
 {
     if (!c) return;
@@ -163,12 +188,15 @@ extern "C" void rope_destroy(rope_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
                     c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_table, c->d_zero_total, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
-                    c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_PVs, c->d_view_of, c->d_frame_of, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
+                    c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->h_vstage) (void)hipHostFree(c->h_vstage);
+    if (c->h_vsums) (void)hipHostFree(c->h_vsums);
+    if (c->h_copy) (void)hipHostFree(c->h_copy);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -290,8 +318,9 @@ extern "C" int rope_set_target(rope_ctx *c, const uint64_t *tq, const float *t32
     if (!tq || !link_flags) ARG_FAIL(c, "rope_set_target: null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
     size_t n = (size_t)c->fp.W * c->fp.H;
-    HIP_TRY(c, hipMemcpyAsync(c->d_tq, tq, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    if (t32) HIP_TRY(c, hipMemcpyAsync(c->d_t32, t32, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int rc = copy_h2d_staged(c, c->d_tq, tq, n * sizeof(uint64_t));
+    if (rc) return rc;
+    if (t32) { rc = copy_h2d_staged(c, c->d_t32, t32, n * sizeof(float)); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_t32 = (t32 != nullptr);
     std::memcpy(c->lf.f, link_flags, 8);
@@ -427,14 +456,14 @@ static RasterArgs base_args(rope_ctx *c, int n_render)
 // forward kinematics + link matrices + screen boxes + tile masks (+ cleared sums) of the resident candidates
 static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const FrameParams &fp, bool views)
 {
-    const double *PV = views ? c->d_PVs : c->d_PV;
-    const int32_t *view_of = views ? c->d_view_of : nullptr;
+    const double *PV = views ? c->dv_PV : c->d_PV, *cand = views ? c->dv_cand : c->d_cand;
+    const int32_t *view_of = views ? c->dv_view_of : nullptr;
     if (c->C <= 256) {                              // one fused launch, one workgroup per candidate
-        HIP_TRY(c, launch_fk_bounds(c->stream, c->d_cand, c->C, fp, c->rp, n_render, n_shared, c->d_joint_fixed, c->d_joint_axes, PV,
+        HIP_TRY(c, launch_fk_bounds(c->stream, cand, c->C, fp, c->rp, n_render, n_shared, c->d_joint_fixed, c->d_joint_axes, PV,
                                     view_of, c->d_mvp, c->d_bounds, c->d_sums, c->d_mask_lo, c->d_mask_hi, c->mask_words));
         return ROPE_OK;
     }
-    HIP_TRY(c, launch_fk(c->stream, c->d_cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
+    HIP_TRY(c, launch_fk(c->stream, cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
                          c->d_mask_lo, c->d_mask_hi, c->mask_words));
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
     return ROPE_OK;
@@ -482,7 +511,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
     a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss & 3]; a.sums = c->d_sums;
-    if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->d_frame_of; }
+    if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->dv_frame_of; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     if (split > 1) {
         int slices = 1;
@@ -671,23 +700,28 @@ extern "C" int rope_set_frames(rope_ctx *c, int n_frames, const double *q, const
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t plane = (size_t)c->fp.W * c->fp.H, n = plane * (size_t)n_frames;
-    HIP_TRY(c, realloc_dev(&c->d_ftq, n));
-    HIP_TRY(c, hipMemcpy(c->d_ftq, tq, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    // buffers only ever grow: a predictor calls this once per run with the same shapes
+    if (n > c->frames_cap) { HIP_TRY(c, realloc_dev(&c->d_ftq, n)); c->frames_cap = n; }
+    int rc = copy_h2d_staged(c, c->d_ftq, tq, n * sizeof(uint64_t));
+    if (rc) return rc;
     c->frames_t32 = (t32 != nullptr);
     if (t32) {
-        HIP_TRY(c, realloc_dev(&c->d_ft32, n));
-        HIP_TRY(c, hipMemcpy(c->d_ft32, t32, n * sizeof(float), hipMemcpyHostToDevice));
+        if (n > c->frames_t32_cap) { HIP_TRY(c, realloc_dev(&c->d_ft32, n)); c->frames_t32_cap = n; }
+        rc = copy_h2d_staged(c, c->d_ft32, t32, n * sizeof(float));
+        if (rc) return rc;
     }
     c->frames_tl = (link_planes != nullptr);
     if (link_planes) {
-        HIP_TRY(c, realloc_dev(&c->d_ftl, n * ROPE_MAX_LINKS));
-        HIP_TRY(c, hipMemcpy(c->d_ftl, link_planes, n * ROPE_MAX_LINKS * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (n * ROPE_MAX_LINKS > c->frames_tl_cap) { HIP_TRY(c, realloc_dev(&c->d_ftl, n * ROPE_MAX_LINKS)); c->frames_tl_cap = n * ROPE_MAX_LINKS; }
+        rc = copy_h2d_staged(c, c->d_ftl, link_planes, n * ROPE_MAX_LINKS * sizeof(uint64_t));
+        if (rc) return rc;
     }
-    HIP_TRY(c, realloc_dev(&c->d_ftotal, (size_t)n_frames * ROPE_SUM_WORDS));
-    HIP_TRY(c, realloc_dev(&c->d_fempty, (size_t)c->n_tiles * ROPE_SUM_WORDS));
+    if (n_frames > c->ftotal_cap) { HIP_TRY(c, realloc_dev(&c->d_ftotal, 5 * (size_t)n_frames * ROPE_SUM_WORDS)); c->ftotal_cap = n_frames; }
+    if (!c->d_fempty) HIP_TRY(c, realloc_dev(&c->d_fempty, (size_t)MAX_MASK_WORDS * 32 * ROPE_SUM_WORDS));   // any tile count
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->h_fq.assign(q, q + 6 * (size_t)n_frames);
     c->n_frames = n_frames;
-    c->ftotal_loss = -1;
+    for (bool &v : c->ftotal_valid) v = false;
     return ROPE_OK;
 }
 
@@ -706,42 +740,59 @@ extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_rende
         if (!std::isfinite(PV[i])) ARG_FAIL(c, "rope_eval_views: non-finite view matrix");
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->n_frames, C = K * N;
-    // candidate (k, i) = view k, frame i: joint vector of frame i, scored against frame i's planes
-    std::vector<double> cand(6 * (size_t)C);
-    std::vector<int32_t> view_of((size_t)C), frame_of((size_t)C);
+    int rc = ensure_capacity(c, C);
+    if (rc) return rc;
+    // One pinned block -> one copy: candidate (k, i) = view k, frame i (joint vector of frame i, scored against frame
+    // i's planes) | the K view matrices | view index | frame index
+    const size_t off_pv = 6 * (size_t)C * sizeof(double), off_vo = off_pv + 16 * (size_t)K * sizeof(double),
+                 off_fo = off_vo + (size_t)C * sizeof(int32_t), bytes = off_fo + (size_t)C * sizeof(int32_t);
+    if (bytes > c->vstage_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_vstage) { (void)hipHostFree(c->h_vstage); c->h_vstage = nullptr; }
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_vstage, bytes, hipHostMallocDefault));
+        HIP_TRY(c, realloc_dev(&c->d_vstage, bytes));
+        c->vstage_cap = bytes;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the block may still feed the previous call's copy
+    double *hc = reinterpret_cast<double *>(c->h_vstage);
+    int32_t *hvo = reinterpret_cast<int32_t *>(c->h_vstage + off_vo), *hfo = reinterpret_cast<int32_t *>(c->h_vstage + off_fo);
     for (int k = 0; k < K; k++)
         for (int i = 0; i < N; i++) {
-            std::memcpy(&cand[6 * ((size_t)k * N + i)], &c->h_fq[6 * (size_t)i], 6 * sizeof(double));
-            view_of[(size_t)k * N + i] = k;
-            frame_of[(size_t)k * N + i] = i;
+            std::memcpy(hc + 6 * ((size_t)k * N + i), &c->h_fq[6 * (size_t)i], 6 * sizeof(double));
+            hvo[(size_t)k * N + i] = k;
+            hfo[(size_t)k * N + i] = i;
         }
-    int rc = upload_candidates(c, cand.data(), C, false);
-    if (rc) return rc;
-    if (K > c->views_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, realloc_dev(&c->d_PVs, 16 * (size_t)K)); c->views_cap = K; }
-    if (C > c->vf_cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, realloc_dev(&c->d_view_of, (size_t)C));
-        HIP_TRY(c, realloc_dev(&c->d_frame_of, (size_t)C));
-        c->vf_cap = C;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->d_PVs, PV, 16 * (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_view_of, view_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_frame_of, frame_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->h_vstage + off_pv, PV, 16 * (size_t)K * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_vstage, c->h_vstage, bytes, hipMemcpyHostToDevice, c->stream));
+    c->dv_cand = reinterpret_cast<const double *>(c->d_vstage);
+    c->dv_PV = reinterpret_cast<const double *>(c->d_vstage + off_pv);
+    c->dv_view_of = reinterpret_cast<const int32_t *>(c->d_vstage + off_vo);
+    c->dv_frame_of = reinterpret_cast<const int32_t *>(c->d_vstage + off_fo);
+    c->C = C;
+    c->n_layers = C;                                  // every (view, frame) candidate is its own layer: nothing shared
     const size_t plane = (size_t)c->fp.W * c->fp.H;
-    if (c->ftotal_loss != loss) {
+    uint64_t *ftotal = c->d_ftotal + (size_t)loss * c->ftotal_cap * ROPE_SUM_WORDS;     // one block of totals per loss kind
+    if (!c->ftotal_valid[loss]) {
         // sums of every frame with nothing rendered: the raster launch only adds what the render changes
         for (int i = 0; i < N; i++)
             HIP_TRY(c, launch_empty(loss, c->stream, c->fp, c->d_ftq + (size_t)i * plane, c->frames_t32 ? c->d_ft32 + (size_t)i * plane : nullptr,
                                     c->frames_tl ? c->d_ftl + (size_t)i * plane * ROPE_MAX_LINKS : nullptr, c->d_fempty,
-                                    c->d_ftotal + (size_t)i * ROPE_SUM_WORDS));
-        c->ftotal_loss = loss;
+                                    ftotal + (size_t)i * ROPE_SUM_WORDS));
+        c->ftotal_valid[loss] = true;
     }
     rc = enqueue_eval(c, n_render, loss, c->fp, (double)plane, nullptr, true);
     if (rc) return rc;
-    std::vector<uint64_t> total((size_t)N * ROPE_SUM_WORDS);
-    HIP_TRY(c, hipMemcpyAsync(sums_out, c->d_sums, (size_t)C * ROPE_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(total.data(), c->d_ftotal, total.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    const size_t n_sums = (size_t)C * ROPE_SUM_WORDS, n_tot = (size_t)N * ROPE_SUM_WORDS;
+    if (n_sums + n_tot > c->vsums_cap) {
+        if (c->h_vsums) { (void)hipHostFree(c->h_vsums); c->h_vsums = nullptr; }
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_vsums, (n_sums + n_tot) * sizeof(uint64_t), hipHostMallocDefault));
+        c->vsums_cap = n_sums + n_tot;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_vsums, c->d_sums, n_sums * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_vsums + n_sums, ftotal, n_tot * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t *total = c->h_vsums + n_sums;
+    std::memcpy(sums_out, c->h_vsums, n_sums * sizeof(uint64_t));
     const bool links = (loss == ROPE_LOSS_CAMFULL);
     for (int k = 0; k < K; k++)
         for (int i = 0; i < N; i++)

@@ -54,15 +54,18 @@ def camfull_error(sums: np.ndarray, n_pix: float, flags: np.ndarray) -> np.ndarr
     flags bit 0: link has a target in that frame; bit 1: more than 5 % of its mask carries depth (:955)."""
     s = sums.astype(np.float64)
     K, N = s.shape[:2]
-    err = np.zeros((K, N))
+    flags = np.asarray(flags)
     with np.errstate(all='ignore'):
+        # all six links at once; the additions below then run term by term in the reference's order
+        L = s[..., S_LINK0:S_LINK0 + 18].reshape(K, N, 6, 3)
+        has = ((flags & 1) != 0)[None]
+        cnt = L[..., 1]
+        mism = np.where(has, L[..., 0] / n_pix, 0.0)
+        depth = np.where(has & ((flags & 2) != 0)[None] & (cnt > 0), (L[..., 2] * 2.0 ** -32) / np.where(cnt > 0, cnt, 1.0), 0.0)
+        err = np.zeros((K, N))
         for l in range(6):
-            has = (flags[:, l] & 1) != 0
-            mism = s[..., S_LINK0 + 3 * l] / n_pix
-            cnt, tot = s[..., S_LINK0 + 3 * l + 1], s[..., S_LINK0 + 3 * l + 2] * 2.0 ** -32
-            depth = np.where(((flags[:, l] & 2) != 0)[None] & (cnt > 0), tot / np.where(cnt > 0, cnt, 1.0), 0.0)
-            err += np.where(has[None], mism, 0.0)          # term by term, in the reference's order of additions
-            err += np.where(has[None], depth, 0.0)
+            err += mism[..., l]
+            err += depth[..., l]
         n = s[..., S_CNT]
         m = (s[..., S_AA] * 2.0 ** -32) / n              # mean of sqrt|T - D| over its non-zero entries
         var = np.maximum((s[..., S_S1] * 2.0 ** -32) / n - m * m, 0.0)
