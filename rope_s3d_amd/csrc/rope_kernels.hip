@@ -5,17 +5,21 @@
 //                           candidate's accumulators (stands in for klampt FK,
 //                           robotpose/simulation/kinematics.py:36-55, and pyrender's node poses, render.py:88-90)
 //   bounds_kernel           per (meshlet, candidate): screen box + the candidate's masks of touched tiles
-//   raster_score_kernel     per (128x48 screen tile, row): meshlet list, vertex shading, triangle cull and
+//   fk_bounds_kernel        batches of <= 256 rows: the two above in one launch, one workgroup per candidate
+//   raster_score_kernel     per (128x96 screen tile, row): meshlet list, vertex shading, triangle cull and
 //     <LOSS, MODE>          set-up, z-test into an LDS depth/id tile, then the loss terms of the covered samples
 //                           as exact integer sums (stands in for pyrender's SEG pass, render.py:92-98, and
 //                           Predictor._error / the lookup reduction, predict.py:475-509,165-171).  Modes:
 //                             LAYER  links 0-2 once per distinct (q0,q1) -> key tiles + their loss sums in HBM
-//                             SCORE  a candidate's remaining links on top of its layer; loss delta
+//                             SCORE  a candidate's remaining links, merged with its layer by min; loss delta
 //                             SPLIT  few candidates: a tile's meshlets over several workgroups, merged by atomicMin
 //                             TABLE  rows of the stored lookup table (cropped sqrt-depth)
 //                             DUMP / COVER  single-pose render, crop search
+//   score_gtile_kernel      after SPLIT: scores the merged images in row bands and hands the buffer back empty
 //   finalize_argmin_kernel  integer sums -> float64 errors, wave-shuffle argmin
 //   table_score_kernel      Lookup stage against the stored table: pure streaming
+//   camera-pose path        the same kernels with a view matrix per candidate (fk) and target planes per frame
+//                           (RasterArgs::frame_of); ROPE_LOSS_CAMFULL = CameraPredictor._error's sums
 //
 // Arithmetic contract: all floating point steps are single IEEE-754
 // operations in the written order (built with -ffp-contract=off; fmaf where fused),
