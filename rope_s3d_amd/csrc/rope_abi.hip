@@ -479,7 +479,8 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
     }
     HIP_TRY(c, launch_fk(c->stream, cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
                          c->d_mask_lo, c->d_mask_hi, c->mask_words));
-    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words));
+    HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words,
+                             n_shared > 0 ? c->d_layer_of : nullptr, n_shared > 0 ? c->d_layer_rep : nullptr));
     return ROPE_OK;
 }
 
@@ -522,7 +523,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
         la.layer_sums = c->d_layer_sums; la.tq = c->d_tq; la.t32 = c->d_t32;
         HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
-        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
+        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
     a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss & 3]; a.sums = c->d_sums;
     if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->dv_frame_of; }
@@ -670,7 +671,7 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
         RasterArgs la = a;
         la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
         HIP_TRY(c, launch_raster(MODE_LAYER, ROPE_LOSS_DEPTH, c->n_layers, c->stream, c->fp, c->rp, la));
-        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layers = c->d_layers;
+        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers;
     }
     a.table = c->d_table;
     HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a));

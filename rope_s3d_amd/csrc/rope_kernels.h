@@ -80,6 +80,7 @@ struct RasterArgs {
     int mask_words;
     const int32_t *cand_of_row;           // MODE_LAYER: layer -> representative candidate; else nullptr
     const int32_t *layer_of;              // candidate -> layer, nullptr when layers are not in use
+    const int32_t *layer_rep;             // layer -> representative candidate (with layer_of)
     uint32_t *layers;                     // n_layers x n_tiles x (TILE_W*TILE_H) keys
     uint64_t *layer_sums;                 // n_layers x n_tiles x ROPE_SUM_WORDS: loss sums of the layer alone
     const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
@@ -100,7 +101,9 @@ hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, co
                      uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
-                         const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
+                         const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
+                         const int32_t *layer_of /* with layer_rep: shared links only for representatives; or nullptr */,
+                         const int32_t *layer_rep);
 // small batches: launch_fk + launch_bounds as one kernel, one workgroup per candidate
 hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const FrameParams &fp, const RobotParams &rp, int n_render,
                             int n_shared, const double *joint_fixed, const double *joint_axes, const double *PV,

@@ -449,14 +449,21 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
 
 __global__ void __launch_bounds__(256)
 bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const float *__restrict__ mvp_all,
-              short4 *__restrict__ bounds, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words)
+              short4 *__restrict__ bounds, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words,
+              const int32_t *__restrict__ layer_of, const int32_t *__restrict__ layer_rep)
 {
     __shared__ uint32_t s_mask[2][MAX_MASK_WORDS];      // [0]: links < n_shared, [1]: the others
     const int cand = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) s_mask[0][i] = s_mask[1][i] = 0;
     __syncthreads();
-    if (m < rp.n_meshlets)
-        bounds[(size_t)cand * rp.n_meshlets + m] = meshlet_box(fp, rp, m, n_render, n_shared, mvp_all + (size_t)cand * ROPE_MAX_LINKS * 16, s_mask);
+    // the shared links are only ever drawn for a layer's representative candidate: the others need neither their
+    // boxes nor their tile mask (raster_score_kernel reads the representative's mask_lo)
+    const bool shared_elsewhere = n_shared > 0 && layer_of && layer_rep[layer_of[cand]] != cand;
+    if (m < rp.n_meshlets) {
+        const bool skip = shared_elsewhere && (int)rp.ml_header[8 * m + 7] < n_shared;
+        bounds[(size_t)cand * rp.n_meshlets + m] =
+            skip ? make_short4(1, 0, 1, 0) : meshlet_box(fp, rp, m, n_render, n_shared, mvp_all + (size_t)cand * ROPE_MAX_LINKS * 16, s_mask);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) {
         if (s_mask[0][i]) atomicOr(&mask_lo[(size_t)cand * mask_words + i], s_mask[0][i]);
@@ -673,7 +680,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 
     // tiles no meshlet of this candidate can touch keep their "empty" sums: nothing to do
     const size_t mw = (size_t)cand * ra.mask_words + (tile_id >> 5);
-    const bool hit_lo = (ra.mask_lo[mw] >> (tile_id & 31)) & 1u, hit_hi = (ra.mask_hi[mw] >> (tile_id & 31)) & 1u;
+    // tiles of the shared links: kept for the layer's representative candidate only (bounds_kernel)
+    const size_t mw_lo = (MODE != MODE_LAYER && ra.layer_of) ? (size_t)ra.layer_rep[ra.layer_of[cand]] * ra.mask_words + (tile_id >> 5) : mw;
+    const bool hit_lo = (ra.mask_lo[mw_lo] >> (tile_id & 31)) & 1u, hit_hi = (ra.mask_hi[mw] >> (tile_id & 31)) & 1u;
     if (MODE == MODE_LAYER ? !hit_lo : !(hit_lo || hit_hi)) return;
     if (fp.debug & 1) return;
     // shared layer (links below l_begin, rendered once per distinct upstream pose) covering this tile
@@ -1217,11 +1226,12 @@ hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, co
 }
 
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
-                         const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words)
+                         const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
+                         const int32_t *layer_of, const int32_t *layer_rep)
 {
     // the masks were cleared by fk_mvp_kernel earlier in the same pass
     hipLaunchKernelGGL(bounds_kernel, dim3((rp.n_meshlets + 255) / 256, C), dim3(256), 0, st, fp, rp, n_render, n_shared, mvp,
-                       bounds, mask_lo, mask_hi, mask_words);
+                       bounds, mask_lo, mask_hi, mask_words, layer_of, layer_rep);
     return hipGetLastError();
 }
 
