@@ -8,6 +8,7 @@ from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
 from rope_s3d_amd.projection import Intrinsics, view_matrix
 
 import helpers
+from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -176,3 +177,45 @@ def test_more_candidates_than_one_launch_holds():
     ref, _, bi0, be0 = e.eval(base, 6, eng.LOSS_DEPTH)
     assert err.shape == (70000,) and np.array_equal(err.reshape(70, 1000).view(np.uint64), np.tile(ref.view(np.uint64), (70, 1)))
     assert bi == bi0 and be == be0                                     # first occurrence wins across launches too
+
+
+@pytest.mark.parametrize('seed', list(range(1, 13)))
+def test_random_scenes_against_oracle(seed):
+    """Random cameras (near, oblique, partly off-screen), all six joints anywhere in their limits, any number of rendered
+    links, odd image sizes, every loss, batch sizes on both sides of the small-batch split: sums and errors bit for bit."""
+    from rope_s3d_amd.urdf import URDFReader
+    rng = np.random.default_rng(seed)
+    rb = helpers.robot()
+    full_lim = URDFReader().joint_limits
+    ds = int(rng.choice([3, 4, 5, 7]))
+    pose = np.array([0, -1.5, 0.75, 0, 0, 0], float) + rng.uniform(-1, 1, 6) * np.array([.6, .6, .4, .25, .25, .4])
+    e, intr, PV = make_engine(rb, '640_480_color', pose=pose, ds=1)
+    # a size no preset produces: crop the projection to W x H by rebuilding the camera at the odd resolution
+    W, H = 640 // ds + int(rng.integers(0, 3)), 480 // ds + int(rng.integers(0, 3))
+    from rope_s3d_amd.constants import ZFAR, ZNEAR
+    from rope_s3d_amd.projection import Intrinsics, view_matrix
+    it = Intrinsics('640_480_color')
+    P = np.zeros((4, 4))
+    P[0, 0], P[1, 1] = 2 * it.fx / ds / W, 2 * it.fy / ds / H
+    P[0, 2], P[1, 2] = 1 - 2 * it.cx / ds / W, 2 * it.cy / ds / H - 1
+    P[2, 2], P[2, 3], P[3, 2] = (ZFAR + ZNEAR) / (ZNEAR - ZFAR), 2 * ZFAR * ZNEAR / (ZNEAR - ZFAR), -1
+    PV = P @ view_matrix(pose)
+    e.set_camera(PV, W, H, ZNEAR, ZFAR)
+    o = orc.Oracle(rb.verts, rb.faces, rb.vtx_off, rb.tri_off, rb.joint_fixed, rb.joint_axes, PV, W, H, ZNEAR, ZFAR)
+    q_t = rng.uniform(full_lim[:, 0], full_lim[:, 1])
+    d, ids = o.render(q_t, 6)
+    tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+    e.set_target(tq, t32, flags)
+    for C in (3, 40, 300):
+        cand = rng.uniform(full_lim[:, 0], full_lim[:, 1], (C, 6))
+        cand[: C // 2, :2] = cand[0, :2]                   # some rows share their first two joints: layers may engage
+        for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL, eng.LOSS_TSWEEP):
+            n = int(rng.integers(1, 7))
+            err, sums, bi, be = e.eval(cand, n, loss, want_sums=True)
+            err_ref, sums_ref = o.eval(cand[:40], loss, n, tq, t32, None, flags, threads=8, want_sums=True)
+            assert np.array_equal(sums[:40], sums_ref), (seed, C, loss, n, W, H)
+            assert np.array_equal(err[:40].view(np.uint64), err_ref.view(np.uint64))
+        crop = [int(H * .2), int(H * .8), int(W * .1), int(W * .9)]
+        err, sums, *_ = e.eval(cand[:40], 6, eng.LOSS_LOOKUP, crop=crop, want_sums=True)
+        err_ref, sums_ref = o.eval(cand[:40], eng.LOSS_LOOKUP, 6, tq, t32, crop, flags, threads=8, want_sums=True)
+        assert np.array_equal(sums, sums_ref) and np.array_equal(err.view(np.uint64), err_ref.view(np.uint64))
