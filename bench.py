@@ -85,6 +85,9 @@ def main():
                          "mh50, 1280x720, 32^3 candidates")
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--split-candidates', action='store_true',
+                    help="strong scaling (SURVEY §8e, optional): ONE frame, its candidates split over the ranks, all-gather of "
+                         "(best error, best index) and a global argmin; default is one frame per rank (weak scaling)")
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL over xGMI); 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
@@ -132,13 +135,20 @@ def main():
     e.set_camera(PV, W, H, ZNEAR, ZFAR)
 
     # synthetic frame of this rank: pose uniform in the S/L/U limits, target = engine render
-    rng = np.random.default_rng(7919 + rank)
+    rng = np.random.default_rng(7919 + (0 if args.split_candidates else rank))
     q_true = rng.uniform(robot.joint_limits[:, 0], robot.joint_limits[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
     depth, ids = e.render(q_true, 6)
     tq = eng.pack_target(depth.astype(np.float64))
     e.set_target(tq, None, np.zeros(8, np.uint8))
 
     cand = slu_grid(robot.joint_limits, args.grid)
+    C_total = len(cand)
+    first = 0
+    if args.split_candidates:
+        # contiguous blocks: the grid has joint 0 fastest, so a block keeps whole (q0, q1) groups together for the layers
+        per = -(-C_total // world)
+        first = rank * per
+        cand = cand[first:first + per]
     C = len(cand)
     e.upload_candidates(cand)
 
@@ -151,7 +161,7 @@ def main():
         e.eval_resident(6, eng.LOSS_DEPTH)
     e.sync()
 
-    best = torch.zeros(6, dtype=torch.float64, device=coll_dev)
+    best = torch.zeros(8 if args.split_candidates else 6, dtype=torch.float64, device=coll_dev)
     if world > 1:                                # part of the warm-up: the collective's first call sets up its channels
         dist.all_gather([torch.zeros_like(best) for _ in range(world)], best)
     barrier()
@@ -160,10 +170,17 @@ def main():
     # on the engine's own stream (torch.cuda.Event would only see torch's current stream)
     kern = e.profile_eval(6, eng.LOSS_DEPTH, None, reps=args.steps)
     _, _, bi, be = e.download(want_err=False)
-    best.copy_(torch.from_numpy(cand[bi]))
+    if args.split_candidates:
+        best.copy_(torch.from_numpy(np.concatenate([cand[bi], [be, first + bi]])))
+    else:
+        best.copy_(torch.from_numpy(cand[bi]))
     if world > 1:
         gathered = [torch.zeros_like(best) for _ in range(world)]
-        dist.all_gather(gathered, best)         # the single collective: final joint angles over xGMI
+        dist.all_gather(gathered, best)         # the single collective: final joint angles (+ score and index) over xGMI
+        if args.split_candidates:               # global argmin: smallest error, then smallest index; NaN never wins
+            g = torch.stack(gathered).cpu().numpy()
+            order = np.lexsort((g[:, 7], np.where(np.isnan(g[:, 6]), np.inf, g[:, 6])))
+            be, bi = float(g[order[0], 6]), int(g[order[0], 7])
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -172,17 +189,19 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        poses = world * args.steps * C
+        poses = (C_total if args.split_candidates else world * C) * args.steps
         raster_s = kern['raster'] * 1e-3
         achieved = b_cand * C / raster_s / 1e9
         out = {
             "metric": "rendered+scored candidate poses/sec @%dx%d" % (W, H),
             "value": poses / dt, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.split_candidates else "weak",
             "vs_baseline": None, "dtype": "i32/i64 fixed-point edge functions, f32 depth, u64 Q32 sums",
             "data": "synthetic",
-            "config": {"workload": label % (C, args.grid),
-                       "candidates_per_step": C, "frames_per_rank": 1, "parallelism": f"frames x{world}",
+            "config": {"workload": label % (C_total, args.grid),
+                       "candidates_per_step": C, "frames_per_rank": 1,
+                       "parallelism": f"candidates of one frame /{world}" if args.split_candidates else f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
