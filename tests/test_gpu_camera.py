@@ -169,3 +169,32 @@ def test_spiral_search_matches_reference(big_renderer):
     assert np.array_equal(got, want)
     # the frames are restored after the spiral: the sweep that follows scores each frame at its own joints
     assert np.array_equal(p.trace[1][1], trace[1][1])
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_random_views_and_frames_against_oracle(seed):
+    """Random frames, random trial cameras (some looking partly away), odd frame counts: sums of both losses bit for bit."""
+    from rope_s3d_amd import engine as eng
+    rng = np.random.default_rng(100 + seed)
+    rb = helpers.robot()
+    intr, o, P = _oracle_side(rb, ds=int(rng.choice([4, 5])))
+    lim = rb.joint_limits
+    N, K = int(rng.integers(1, 5)), int(rng.integers(1, 8))
+    qs = rng.uniform(lim[:, 0], lim[:, 1], (N, 6))
+    true_pose = np.array(DEFAULT_CAMERA_POSE, float) + rng.uniform(-.2, .2, 6)
+    o.PV = np.ascontiguousarray(P @ camera_ref.view_of_pose(true_pose))
+    frames = [o.render(q, 6) for q in qs]
+    tgt = np.stack([d for d, _ in frames]).astype(np.float64)
+    names = rb.link_names[:6]
+    seg = [{n: {'mask': frames[i][1] == l} for l, n in enumerate(names) if (frames[i][1] == l).any()} for i in range(N)]
+    ref = camera_ref.CameraReference(o, P, 'segmented', qs, tgt, seg, names)
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(P @ camera_ref.view_of_pose(DEFAULT_CAMERA_POSE), intr.width, intr.height, ZNEAR, ZFAR)
+    e.set_frames(qs, np.stack([eng.pack_target(d) for d in tgt]), tgt.astype(np.float32), np.tile(ref.planes[None], (N, 1, 1, 1)))
+    poses = true_pose + rng.uniform(-1, 1, (K, 6)) * np.array([.3, .3, .3, .2, .2, .5])
+    PV = np.stack([P @ camera_ref.view_of_pose(p) for p in poses])
+    full, sweep = e.eval_views(PV, 6, eng.LOSS_CAMFULL), e.eval_views(PV, 6, eng.LOSS_TSWEEP)
+    for k in range(K):
+        assert np.array_equal(full[k], ref.frame_sums(poses[k], 'full')), (seed, k)
+        assert np.array_equal(sweep[k][:, :5], ref.frame_sums(poses[k], 'sweep')[:, :5]), (seed, k)
