@@ -42,8 +42,9 @@ def run(args):
         import torch
         from rope_s3d_amd.maskrcnn import MaskRCNNSegmenter
         sd = torch.load(args.weights, map_location='cpu') if getattr(args, 'weights', None) else None
-        kwargs['segmenter'] = MaskRCNNSegmenter(7, device=f'cuda:{gpu}', state_dict=sd,
-                                                min_confidence=0.7 if sd is not None else 0.0)
+        from rope_s3d_amd.maskrcnn import BatchAheadSegmenter
+        kwargs['segmenter'] = BatchAheadSegmenter(MaskRCNNSegmenter(7, device=f'cuda:{gpu}', state_dict=sd,
+                                                                    min_confidence=0.7 if sd is not None else 0.0), batch=8)
     elif ds.attrs.get('synthetic'):
         kwargs['color_dict'] = ds.attrs['color_dict']         # link masks are read from the colour render
     am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
@@ -57,6 +58,9 @@ def run(args):
         og_imgs = np.copy(ds.og_img[start:end])
         dms = np.copy(ds.depthmaps[start:end])
         cam_poses = np.copy(ds.camera_pose[start:end])
+        seg = None if am.synthetic else getattr(am, 'seg', None)
+        if hasattr(seg, 'announce'):                          # the chunk's frames through the network in batches of 8
+            seg.announce([am._downsample(og_imgs[i], am.ds_factor) for i in range(end - start)])
         for i in range(end - start):
             out[start - lo + i] = am.run(og_imgs[i], dms[i], cam_poses[i])
     full = gather_rows(out, ds.length, device=device)

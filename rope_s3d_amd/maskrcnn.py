@@ -243,20 +243,36 @@ class MaskRCNN(nn.Module):
     @torch.no_grad()
     def detect(self, image_rgb: torch.Tensor):
         """image_rgb (H,W,3) uint8 on the module's device -> (class_ids (K,), scores (K,), masks (H,W,K) bool)."""
-        dev = image_rgb.device
-        H, W = image_rgb.shape[:2]
+        return self.detect_batch([image_rgb])[0]
+
+    @torch.no_grad()
+    def detect_batch(self, images):
+        """Several frames of one size at once: the convolutional trunk (backbone, FPN, RPN heads — the dense contraction)
+        runs on the whole batch, proposals / RoIAlign / heads / un-moulding then per frame.  Same results per frame as
+        `detect` up to the batch-size dependence of the convolution algorithms the library picks."""
+        dev = images[0].device
+        H, W = images[0].shape[:2]
         scale = self.size / max(H, W)                                   # resize_image(mode='square')
         nh, nw = round(H * scale), round(W * scale)
         top, left = (self.size - nh) // 2, (self.size - nw) // 2
-        x = image_rgb.permute(2, 0, 1)[None].float()
+        x = torch.stack([im.permute(2, 0, 1) for im in images]).float()
         x = F.interpolate(x, (nh, nw), mode='bilinear', align_corners=False)
         x = x - torch.tensor(MEAN_PIXEL, device=dev).view(1, 3, 1, 1)
         x = F.pad(x, (left, self.size - nw - left, top, self.size - nh - top))
-        window = torch.tensor([top, left, top + nh, left + nw], device=dev, dtype=torch.float32)
         wdt = next(self.parameters()).dtype                              # bf16 on the GPU (cast once), f32 on CPU
-        feats = self.fpn(self.backbone(x.to(wdt).contiguous(memory_format=torch.channels_last)))
-        probs, deltas = zip(*[self.rpn(p) for p in feats])
-        probs, deltas = torch.cat(probs, 1)[0], torch.cat(deltas, 1)[0]
+        feats_all = self.fpn(self.backbone(x.to(wdt).contiguous(memory_format=torch.channels_last)))
+        rpn_all = [self.rpn(p) for p in feats_all]
+        out = []
+        for b in range(len(images)):
+            feats = [f[b:b + 1] for f in feats_all]
+            probs = torch.cat([r[0][b:b + 1] for r in rpn_all], 1)[0]
+            deltas = torch.cat([r[1][b:b + 1] for r in rpn_all], 1)[0]
+            out.append(self._detect_one(feats, probs, deltas, H, W, scale, top, left, nh, nw))
+        return out
+
+    def _detect_one(self, feats, probs, deltas, H, W, scale, top, left, nh, nw):
+        dev = probs.device
+        window = torch.tensor([top, left, top + nh, left + nw], device=dev, dtype=torch.float32)
         anchors = _pyramid_anchors(self.size, dev)
         k = min(PRE_NMS_LIMIT, len(probs))
         top_idx = probs.topk(k).indices
@@ -322,6 +338,38 @@ class MaskRCNNSegmenter:
             self.net = self.net.to(torch.bfloat16).to(memory_format=torch.channels_last)
 
     def __call__(self, color_bgr: np.ndarray) -> dict:
-        rgb = torch.from_numpy(np.ascontiguousarray(color_bgr[..., ::-1])).to(self.device)
-        cls, score, masks = self.net.detect(rgb)
-        return {'class_ids': cls.numpy(), 'scores': score.numpy(), 'masks': masks.numpy()}
+        return self.batch([color_bgr])[0]
+
+    def batch(self, frames) -> list:
+        """Several frames of one size in one pass of the convolutional trunk -> list of result dicts."""
+        rgb = [torch.from_numpy(np.ascontiguousarray(f[..., ::-1])).to(self.device) for f in frames]
+        return [{'class_ids': cls.numpy(), 'scores': score.numpy(), 'masks': masks.numpy()}
+                for cls, score, masks in self.net.detect_batch(rgb)]
+
+
+class BatchAheadSegmenter:
+    """Segments the frames a caller is about to predict in batches, then hands the results out one by one.
+
+    `announce(frames)` takes the down-sampled colour images of the coming frames (any number) and runs them through
+    `segmenter.batch` in groups of `batch`; `__call__(frame)` returns the stored result of that frame (matched by
+    content), or segments it on the spot if it was not announced.  Single-threaded: the point is the batch efficiency
+    of the convolutions, not overlap."""
+
+    def __init__(self, segmenter: MaskRCNNSegmenter, batch: int = 8):
+        self._seg, self._batch, self._store = segmenter, int(batch), {}
+
+    @staticmethod
+    def _key(color: np.ndarray):
+        a = np.ascontiguousarray(color)
+        return (a.shape, a[::5, ::5].tobytes())
+
+    def announce(self, frames):
+        frames = [np.asarray(f) for f in frames]
+        for i in range(0, len(frames), self._batch):
+            group = frames[i:i + self._batch]
+            for f, r in zip(group, self._seg.batch(group)):
+                self._store[self._key(f)] = r
+
+    def __call__(self, color: np.ndarray) -> dict:
+        r = self._store.pop(self._key(color), None)
+        return r if r is not None else self._seg(color)

@@ -82,3 +82,23 @@ def test_device_nms_equals_the_one_by_one_sweep():
         got = _nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr, limit).numpy()
         assert np.array_equal(got, greedy(boxes, scores, thr, limit))
     assert len(_nms(torch.zeros((0, 4)), torch.zeros(0), 0.5, 10)) == 0
+
+
+def test_batched_trunk_gives_the_single_frame_results():
+    """detect_batch runs backbone/FPN/RPN on all frames at once; per frame the results equal detect()'s (CPU float32:
+    the same convolution code path for batch 1 and 2 up to rounding, so boxes may move by a hair but not change class)."""
+    from rope_s3d_amd.maskrcnn import BatchAheadSegmenter
+    seg = MaskRCNNSegmenter(7, device='cpu', seed=0, min_confidence=0.0)
+    rng = np.random.default_rng(1)
+    a, b = rng.integers(0, 255, (45, 80, 3), dtype=np.uint8), rng.integers(0, 255, (45, 80, 3), dtype=np.uint8)
+    ra, rb_ = seg(a), seg(b)
+    both = seg.batch([a, b])
+    for single, batched in ((ra, both[0]), (rb_, both[1])):
+        assert len(single['class_ids']) == len(batched['class_ids'])
+        assert np.array_equal(single['class_ids'], batched['class_ids'])
+        assert np.allclose(single['scores'], batched['scores'], atol=1e-4)
+        assert (single['masks'] != batched['masks']).mean() < 1e-3
+    ahead = BatchAheadSegmenter(seg, batch=2)
+    ahead.announce([a, b])
+    assert np.array_equal(ahead(b)['class_ids'], rb_['class_ids']) and not ahead._store.get(ahead._key(b))
+    assert np.array_equal(ahead(b)['class_ids'], rb_['class_ids'])      # not stored any more: segmented on the spot
