@@ -143,28 +143,49 @@ def _apply_deltas(boxes, deltas):
     return torch.stack([cy - 0.5 * h, cx - 0.5 * w, cy + 0.5 * h, cx + 0.5 * w], 1)
 
 
-def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int) -> torch.Tensor:
+def _iou_over(a: torch.Tensor, b: torch.Tensor, thr: float) -> torch.Tensor:
+    """(len(a), len(b)) bool: IoU(a_i, b_j) > thr, coordinate by coordinate (no stacked temporaries)."""
+    ih = (torch.min(a[:, None, 2], b[None, :, 2]) - torch.max(a[:, None, 0], b[None, :, 0])).clamp_(min=0)
+    iw = (torch.min(a[:, None, 3], b[None, :, 3]) - torch.max(a[:, None, 1], b[None, :, 1])).clamp_(min=0)
+    inter = ih.mul_(iw)
+    area_a = (a[:, 2] - a[:, 0]).clamp(min=0) * (a[:, 3] - a[:, 1]).clamp(min=0)
+    area_b = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
+    return inter / (area_a[:, None] + area_b[None, :] - inter).clamp_(min=1e-12) > thr
+
+
+def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int, block: int = 2048) -> torch.Tensor:
     """Greedy non-maximum suppression (tf.image.non_max_suppression): indices kept, best first.
 
     The greedy rule "box j stays unless an earlier box that stays overlaps it" has exactly one solution; instead of
-    sweeping the boxes one by one it is iterated as a whole on the device — keep <- not any(earlier & keep & overlap) —
-    until nothing changes.  After t rounds at least the first t boxes are final, in practice a dozen rounds settle
-    thousands of boxes: no pairwise matrix leaves the GPU and nothing runs per box on the host."""
+    sweeping the boxes one by one it is iterated as a whole on the device — keep <- alive and not any(earlier & keep &
+    overlap) — until nothing changes (after t rounds at least the first t boxes are final; a dozen rounds settle
+    thousands).  Boxes go through in blocks of `block` by descending score: a block is first thinned by the boxes
+    already kept, then settled internally, and the walk stops as soon as `limit` boxes are kept — most of the
+    pairwise overlaps of a 6000-proposal frame are never computed, and nothing runs per box on the host."""
     if boxes.numel() == 0:
         return torch.zeros(0, dtype=torch.long, device=boxes.device)
     order = scores.argsort(descending=True, stable=True)
     b = boxes[order].float()
-    area = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
-    tl, br = torch.max(b[:, None, :2], b[None, :, :2]), torch.min(b[:, None, 2:], b[None, :, 2:])
-    inter = (br - tl).clamp(min=0).prod(-1)
-    sup = ((inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-12)) > thr).triu_(1)   # [i, j]: earlier i suppresses j
-    keep = torch.ones(len(b), dtype=torch.bool, device=b.device)
-    for _ in range(len(b)):
-        new = ~(sup & keep[:, None]).any(0)
-        if torch.equal(new, keep):
+    kept, kept_boxes, n_kept = [], b[:0], 0
+    for start in range(0, len(b), block):
+        blk = b[start:start + block]
+        alive = torch.ones(len(blk), dtype=torch.bool, device=b.device)
+        if n_kept:
+            alive &= ~_iou_over(kept_boxes, blk, thr).any(0)
+        sup = _iou_over(blk, blk, thr).triu_(1)                       # [i, j]: earlier i suppresses j
+        keep = alive
+        for _ in range(len(blk)):
+            new = alive & ~(sup & keep[:, None]).any(0)
+            if torch.equal(new, keep):
+                break
+            keep = new
+        idx = keep.nonzero().squeeze(1)
+        kept.append(idx + start)
+        kept_boxes = torch.cat([kept_boxes, blk[idx]])
+        n_kept += len(idx)
+        if n_kept >= limit:
             break
-        keep = new
-    return order[keep.nonzero().squeeze(1)[:limit]]
+    return order[torch.cat(kept)[:limit]]
 
 
 def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: int) -> torch.Tensor:

@@ -75,12 +75,13 @@ def test_device_nms_equals_the_one_by_one_sweep():
         return order[keep]
 
     rng = np.random.default_rng(0)
-    for n, thr, limit in ((1500, 0.7, 300), (400, 0.3, 100), (40, 0.5, 1000), (1, 0.5, 10)):
+    for n, thr, limit in ((1500, 0.7, 300), (400, 0.3, 100), (40, 0.5, 1000), (1, 0.5, 10), (5000, 0.7, 1000), (3000, 0.5, 5000)):
         c = rng.random((n, 2)).astype(np.float32)
         wh = (rng.random((n, 2)) * 0.2 + 0.02).astype(np.float32)
         boxes, scores = np.concatenate([c - wh / 2, c + wh / 2], 1), rng.random(n).astype(np.float32)
-        got = _nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr, limit).numpy()
-        assert np.array_equal(got, greedy(boxes, scores, thr, limit))
+        for block in (2048, 300):                    # several blocks, carried-over suppression, early stop at the limit
+            got = _nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr, limit, block=block).numpy()
+            assert np.array_equal(got, greedy(boxes, scores, thr, limit)), (n, thr, limit, block)
     assert len(_nms(torch.zeros((0, 4)), torch.zeros(0), 0.5, 10)) == 0
 
 
