@@ -691,7 +691,7 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
-    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_sums));
+    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_depth /* scratch: H x W floats */, c->d_sums));
     HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_err));
     if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_err, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err + c->table_C, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

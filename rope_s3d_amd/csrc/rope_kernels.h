@@ -118,7 +118,9 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err /* C + 2: errors, best error, best index */);
 // score every row of a stored lookup table against the float32 target plane
-hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, uint64_t *sums);
+// t32c: scratch of crop_h x crop_w floats (the cropped target, rebuilt by every call)
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, float *t32c,
+                              uint64_t *sums);
 hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);
 
 }  // namespace rope

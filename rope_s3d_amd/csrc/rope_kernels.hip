@@ -1064,8 +1064,17 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
 // ------------------------------------------------------------- lookup table -----
 // Lookup stage against a stored table (predict.py:165-171): per row k of the table,
 // the exact sums of |T - sqrtD_k| in Q32 over the crop.  Pure streaming: N*h*w*4 bytes read once.
+// the crop of the target plane as one contiguous row, laid out like a row of the table (no index arithmetic per sample later)
 __global__ void __launch_bounds__(256)
-table_score_kernel(FrameParams fp, const float *__restrict__ table, const float *__restrict__ t32, uint64_t *__restrict__ sums)
+crop_target_kernel(FrameParams fp, const float *__restrict__ t32, float *__restrict__ t32c)
+{
+    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c < cw && r < ch) t32c[(size_t)r * cw + c] = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
+}
+
+__global__ void __launch_bounds__(256)
+table_score_kernel(FrameParams fp, const float *__restrict__ table, const float *__restrict__ t32c, uint64_t *__restrict__ sums)
 {
     __shared__ uint64_t lds[4];
     const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1, n = cw * ch;
@@ -1075,10 +1084,7 @@ table_score_kernel(FrameParams fp, const float *__restrict__ table, const float 
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
     auto one = [&](int i, float d) {
-        const int r = i / cw, c = i - r * cw;
-        const float t = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
-        const uint64_t dq = q32_of_f32(fabsf(t - d));
-        if (dq) acc_sq<false>(s, dq);
+        acc_sq<false>(s, q32_of_f32(fabsf(t32c[i] - d)));       // a zero difference adds zeros: no branch
     };
     // 16-byte loads where the row start allows it (rows are n floats apart, so alignment depends on the row)
     const int head = (int)((4 - (((size_t)blockIdx.x * n) & 3)) & 3);
@@ -1305,9 +1311,12 @@ hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total
     return hipGetLastError();
 }
 
-hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, uint64_t *sums)
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, float *t32c,
+                              uint64_t *sums)
 {
-    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, fp, table, t32, sums);
+    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
+    hipLaunchKernelGGL(crop_target_kernel, dim3((cw + 255) / 256, ch), dim3(256), 0, st, fp, t32, t32c);
+    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, fp, table, t32c, sums);
     return hipGetLastError();
 }
 
