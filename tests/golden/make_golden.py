@@ -58,10 +58,13 @@ def main():
     # crop of six visible links at 160x120 as the product's Crop computes it (checked against the oracle in
     # tests/test_gpu_predictor.py::test_crop_matches_oracle)
     from rope_s3d_amd.crop import crop_pose_grid
-    cover = o.coverage(crop_pose_grid(lim, intr.size, 6)[0], 6, threads=8) != 0
+    cover = helpers.make_oracle(rb, *helpers.camera('640_480_color', ds=4, as_predictor=True)).coverage(crop_pose_grid(lim, intr.size, 6)[0], 6, threads=8) != 0
     r, c = np.where(cover)
     crop6 = np.array([max(r.min() - 10, 0), min(r.max() + 10, intr.height - 1), max(c.min() - 10, 0), min(c.max() + 10, intr.width - 1)], np.int32)
-    final, trace, n_eval = predictor_ref.predict_reference(o, tgt_depth, tgt_blue, names, link_blue, lim, DEFAULT_CAMERA_POSE,
+    # Predictor's renderer works with the intrinsics as rebuilt from their six-digit string form (helpers.camera)
+    intr_p, PV_p = helpers.camera('640_480_color', ds=4, as_predictor=True)
+    o_p = helpers.make_oracle(rb, intr_p, PV_p)
+    final, trace, n_eval = predictor_ref.predict_reference(o_p, tgt_depth, tgt_blue, names, link_blue, lim, DEFAULT_CAMERA_POSE,
                                                            cand, crop6, 'SLU')
     out.update(frame_q_true=q_true, frame_crop6=crop6, frame_final=final, frame_trace=np.stack([a for _, a in trace]),
                frame_evaluations=np.int64(n_eval))

@@ -15,10 +15,14 @@ def robot(urdf: str = None) -> RobotModel:
     return RobotModel.from_urdf(URDFReader(urdf) if urdf else URDFReader())
 
 
-def camera(preset='640_480_color', ds=1, pose=DEFAULT_CAMERA_POSE):
+def camera(preset='640_480_color', ds=1, pose=DEFAULT_CAMERA_POSE, as_predictor=False):
+    """as_predictor: Predictor hands its down-scaled Intrinsics OBJECT to Renderer, whose constructor — like the
+    reference's (projection.py:20-46, render.py:41) — rebuilds it from its string form: six significant digits."""
     intr = Intrinsics(preset)
     if ds != 1:
         intr.downscale(ds)
+    if as_predictor:
+        intr = Intrinsics(intr)
     PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(pose)
     return intr, PV
 

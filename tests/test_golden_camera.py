@@ -73,9 +73,9 @@ def test_predictors_reproduce_camera_golden_traces(cpu, mode):
                 'scores': np.ones(len(seg[k])), 'masks': np.stack([seg[k][n]['mask'] for n in names if n in seg[k]], -1)}
     colors = np.stack([np.full(tgt.shape[1:] + (3,), i, np.uint8) for i in range(len(qs))])
     if mode == 'modelless':
-        p = ModellessCameraPredictor(DEFAULT_CAMERA_POSE, 1, base_intrinsics=intr)
+        p = ModellessCameraPredictor(DEFAULT_CAMERA_POSE, 1, base_intrinsics='640_480_color_4')   # exact: no string round trip
     else:
-        p = CameraPredictor(DEFAULT_CAMERA_POSE, 1, base_intrinsics=intr, segmenter=segmenter)
+        p = CameraPredictor(DEFAULT_CAMERA_POSE, 1, base_intrinsics='640_480_color_4', segmenter=segmenter)
     p.stages = [tuple(s) for s in mk.SHORT_STAGES]
     got = p.run(colors, tgt, qs)
     assert np.array_equal(np.stack([a for _, a in p.trace]), G[f'trace_{mode}'])
