@@ -105,10 +105,11 @@ def test_eval_views_argument_errors(big_renderer):
     assert s.shape == (1, 1, 23) and int(s[0, 0, 0]) == int((d != 0).sum())
 
 
-def test_modelless_predictor_trace_matches_sequential_reference(big_renderer):
+@pytest.mark.parametrize('fseed', [33 + k for k in range(int(__import__('os').environ.get('ROPE_CAM_TRACE_SEEDS', '1')))])
+def test_modelless_predictor_trace_matches_sequential_reference(big_renderer, fseed):
     from rope_s3d_amd import ModellessCameraPredictor
     rb = helpers.robot()
-    qs, colors, depths = _frames(big_renderer, rb, 2, 33)
+    qs, colors, depths = _frames(big_renderer, rb, 2, fseed)
     start = np.array(DEFAULT_CAMERA_POSE, float)
     p = ModellessCameraPredictor(start, 4, base_intrinsics='640_480_color')
     got = p.run(colors, depths, qs)
@@ -126,12 +127,13 @@ def test_modelless_predictor_trace_matches_sequential_reference(big_renderer):
     assert p.error_at(got) <= p.error_at(start)
 
 
-def test_segmented_predictor_trace_matches_sequential_reference(big_renderer):
+@pytest.mark.parametrize('fseed', [34 + 7 * k for k in range(int(__import__('os').environ.get('ROPE_CAM_TRACE_SEEDS', '1')))])
+def test_segmented_predictor_trace_matches_sequential_reference(big_renderer, fseed):
     from rope_s3d_amd import CameraPredictor
     from rope_s3d_amd.segmentation import ColorSegmenter
     rb = helpers.robot()
     names = rb.link_names[:6]
-    qs, colors, depths = _frames(big_renderer, rb, 2, 34)
+    qs, colors, depths = _frames(big_renderer, rb, 2, fseed)
     start = np.array(DEFAULT_CAMERA_POSE, float)
     segf = ColorSegmenter(['BG'] + names, split_instances=True)
     p = CameraPredictor(start, 4, base_intrinsics='640_480_color', segmenter=segf)
