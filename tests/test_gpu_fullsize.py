@@ -219,3 +219,26 @@ def test_random_scenes_against_oracle(seed):
         err, sums, *_ = e.eval(cand[:40], 6, eng.LOSS_LOOKUP, crop=crop, want_sums=True)
         err_ref, sums_ref = o.eval(cand[:40], eng.LOSS_LOOKUP, 6, tq, t32, crop, flags, threads=8, want_sums=True)
         assert np.array_equal(sums, sums_ref) and np.array_equal(err.view(np.uint64), err_ref.view(np.uint64))
+
+
+@pytest.mark.parametrize('seed', list(range(1, 1 + int(__import__('os').environ.get('ROPE_RENDER_SEEDS', '4')))))
+def test_random_full_resolution_renders_against_oracle(seed):
+    """Both robots at their full resolutions under random cameras and joint vectors: depth and link-id images bit for bit
+    (the close cameras put triangles across the image border, behind the eye and hundreds of pixels wide)."""
+    from rope_s3d_amd.urdf import URDFReader
+    rng = np.random.default_rng(500 + seed)
+    big = seed % 2 == 0
+    urdf = 'urdfs/motoman_mh50_support/urdf/mh50.urdf' if big else None
+    rb = helpers.robot(urdf)
+    lim = URDFReader(urdf).joint_limits if urdf else URDFReader().joint_limits
+    base = np.array([0, -4.0, 1.5, 0, 0, 0] if big else [0, -1.5, 0.75, 0, 0, 0], float)
+    pose = base + rng.uniform(-1, 1, 6) * np.array([.8, .8, .5, .3, .3, .5]) * (2.5 if big else 1.0) * np.array([1, 1, 1, .4, .4, .4])
+    e, intr, PV = make_engine(rb, '1280_720_color' if big else '640_480_color', pose)
+    o = helpers.make_oracle(rb, intr, PV)
+    for _ in range(2):
+        q = rng.uniform(lim[:, 0], lim[:, 1])
+        n = int(rng.integers(1, 7))
+        d_ref, id_ref = o.render(q, n)
+        d, ids = e.render(q, n)
+        assert np.array_equal(ids, id_ref), (seed, n, int((ids != id_ref).sum()))
+        assert np.array_equal(d.view(np.uint32), d_ref.view(np.uint32)), (seed, n)
