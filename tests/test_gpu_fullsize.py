@@ -242,3 +242,29 @@ def test_random_full_resolution_renders_against_oracle(seed):
         d, ids = e.render(q, n)
         assert np.array_equal(ids, id_ref), (seed, n, int((ids != id_ref).sum()))
         assert np.array_equal(d.view(np.uint32), d_ref.view(np.uint32)), (seed, n)
+
+
+def test_full_grid_sample_against_oracle(full):
+    """The bench workload itself (4096 candidates, 640x480, shared layers, big-batch path): a random sample of its rows
+    against the oracle, sums and errors bit for bit, for the depth-only and the full loss; and the 1280x720 grid of cfg5."""
+    rb, e, q_true, depth, ids, (tq, t32, flags) = full
+    intr, PV = helpers.camera('640_480_color')
+    o = helpers.make_oracle(rb, intr, PV)
+    cand = helpers.slu_grid(rb.joint_limits, 16)
+    pick = np.sort(np.random.default_rng(17).choice(len(cand), 48, replace=False))
+    for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL):
+        err, sums, *_ = e.eval(cand, 6, loss, want_sums=True)
+        err_ref, sums_ref = o.eval(cand[pick], loss, 6, tq, t32, None, flags, threads=8, want_sums=True)
+        assert np.array_equal(sums[pick], sums_ref), loss
+        assert np.array_equal(err[pick].view(np.uint64), err_ref.view(np.uint64)), loss
+    rb5 = helpers.robot('urdfs/motoman_mh50_support/urdf/mh50.urdf')
+    e5, intr5, PV5 = make_engine(rb5, '1280_720_color', [0, -4.0, 1.5, 0, 0, 0])
+    o5 = helpers.make_oracle(rb5, intr5, PV5)
+    d5, i5 = e5.render([0.4, 0.3, 0.2, 0, 0, 0], 6)
+    tq5, t325, fl5, *_ = helpers.synthetic_target(d5, i5)
+    e5.set_target(tq5, t325, fl5)
+    cand5 = helpers.slu_grid(rb5.joint_limits, 12)
+    pick5 = np.sort(np.random.default_rng(18).choice(len(cand5), 24, replace=False))
+    err, sums, *_ = e5.eval(cand5, 6, eng.LOSS_DEPTH, want_sums=True)
+    err_ref, sums_ref = o5.eval(cand5[pick5], eng.LOSS_DEPTH, 6, tq5, t325, None, fl5, threads=8, want_sums=True)
+    assert np.array_equal(sums[pick5], sums_ref) and np.array_equal(err[pick5].view(np.uint64), err_ref.view(np.uint64))
