@@ -135,8 +135,8 @@ int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop
 /* Profiling aid, never used by the product path: bit mask of kernel phases to skip
  * (1 meshlet culling onward, 2 vertex shading onward, 4 triangle set-up, 8 pixel loop, 16 loss pass,
 
- * 32 small-triangle loops, 64 row pass, 128 disables shared upstream layers, 1024 disables the small-batch split —
- * results stay exact for 128 and 1024).
+ * 32 small-triangle loops, 64 row pass, 128 disables shared upstream layers, 1024 disables the small-batch split,
+ * 2048 disables the second level of layer sharing — results stay exact for 128, 1024 and 2048).
  * Results are meaningless while a bit is set. */
 int rope_debug_skip(rope_ctx *ctx, int mask);
 

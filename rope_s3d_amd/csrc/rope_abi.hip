@@ -64,6 +64,12 @@ struct rope_ctx {
     uint32_t *d_layers = nullptr;
     uint64_t *d_layer_sums = nullptr;
     size_t layers_cap = 0;                 // keys allocated in d_layers
+    // second level of sharing: layers with bit-identical q0 have identical links 0..1 ("parents")
+    int n_parents = 0;
+    int32_t *d_parent_of = nullptr, *d_parent_rep = nullptr;   // layer -> parent; parent -> representative candidate
+    uint32_t *d_parents = nullptr;
+    size_t parents_cap = 0;
+    int parent_idx_cap = 0;
     int layer_rep_cap = 0;
     uint64_t *d_sums = nullptr;
     int32_t *d_best_idx = nullptr;
@@ -201,7 +207,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_table, c->d_zero_total, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_zero_total, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -394,12 +400,18 @@ static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
             keys[i].idx = i;
         }
         std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.idx < y.idx); });
-        std::vector<int32_t> layer_of((size_t)C), layer_rep;
+        std::vector<int32_t> layer_of((size_t)C), layer_rep, parent_of, parent_rep;
         for (int i = 0; i < C; i++) {
-            if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) layer_rep.push_back(keys[i].idx);
+            if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) {
+                layer_rep.push_back(keys[i].idx);
+                // layers come out sorted by q0: a new q0 opens a new parent, represented by this layer's own candidate
+                if (i == 0 || keys[i].a != keys[i - 1].a) parent_rep.push_back(keys[i].idx);
+                parent_of.push_back((int32_t)parent_rep.size() - 1);
+            }
             layer_of[keys[i].idx] = (int32_t)layer_rep.size() - 1;
         }
         c->n_layers = (int)layer_rep.size();
+        c->n_parents = (int)parent_rep.size();
         if (c->n_layers * 4 <= C) {                // same rule as want_layers(): only then are the arrays read
             if (c->n_layers > c->layer_rep_cap) {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -408,6 +420,16 @@ static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
             }
             HIP_TRY(c, hipMemcpyAsync(c->d_layer_of, layer_of.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipMemcpyAsync(c->d_layer_rep, layer_rep.data(), layer_rep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            if (c->n_parents * 4 <= c->n_layers) {     // same rule one level up (want_parents())
+                if (c->n_layers > c->parent_idx_cap) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    HIP_TRY(c, realloc_dev(&c->d_parent_of, (size_t)c->n_layers));
+                    HIP_TRY(c, realloc_dev(&c->d_parent_rep, (size_t)c->n_layers));
+                    c->parent_idx_cap = c->n_layers;
+                }
+                HIP_TRY(c, hipMemcpyAsync(c->d_parent_of, parent_of.data(), parent_of.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(c->d_parent_rep, parent_rep.data(), parent_rep.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            }
             HIP_TRY(c, hipStreamSynchronize(c->stream));   // layer_of / layer_rep are stack-local
         }
     }
@@ -455,6 +477,32 @@ static int ensure_layers(rope_ctx *c)
     HIP_TRY(c, realloc_dev(&c->d_layers, need));
     HIP_TRY(c, realloc_dev(&c->d_layer_sums, (size_t)c->n_layers * c->n_tiles * ROPE_SUM_WORDS));
     c->layers_cap = need;
+    return ROPE_OK;
+}
+
+static bool want_parents(const rope_ctx *c) { return c->n_parents * 4 <= c->n_layers; }
+
+// The shared links of every layer into c->d_layers (+ their loss sums when `la` carries targets and layer_sums).
+// Two levels when many layers share their first joint angle: links 0-1 once per distinct q0, then link 2 per layer
+// merged with its parent's tile.
+static int enqueue_layers(rope_ctx *c, RasterArgs la, int loss, int n_shared, const FrameParams &fp)
+{
+    la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
+    if (n_shared == 3 && want_parents(c) && !(fp.debug & 2048)) {
+        const size_t need = (size_t)c->n_parents * c->n_tiles * (TILE_W * TILE_H);
+        if (need > c->parents_cap) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, realloc_dev(&c->d_parents, need));
+            c->parents_cap = need;
+        }
+        RasterArgs pa = la;
+        pa.l_begin = 0; pa.l_end = 2; pa.cand_of_row = c->d_parent_rep; pa.layers = c->d_parents; pa.layer_sums = nullptr;
+        HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_parents, c->stream, fp, c->rp, pa));
+        la.l_begin = 2; la.l_end = 3; la.base_layers = c->d_parents; la.base_of_row = c->d_parent_of; la.base_rep = c->d_parent_rep;
+    } else {
+        la.l_begin = 0; la.l_end = n_shared;
+    }
+    HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
     return ROPE_OK;
 }
 
@@ -520,9 +568,8 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     }
     if (layers) {
         RasterArgs la = a;
-        la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
         la.layer_sums = c->d_layer_sums; la.tq = c->d_tq; la.t32 = c->d_t32;
-        HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
+        { int rc = enqueue_layers(c, la, loss, n_shared, fp); if (rc) return rc; }
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
     a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss & 3]; a.sums = c->d_sums;
@@ -668,9 +715,8 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
     RasterArgs a = base_args(c, n_render);
     if (layers) {
         // layer pass without loss sums (layer_sums == nullptr): no target is needed to build a table
-        RasterArgs la = a;
-        la.l_begin = 0; la.l_end = n_shared; la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
-        HIP_TRY(c, launch_raster(MODE_LAYER, ROPE_LOSS_DEPTH, c->n_layers, c->stream, c->fp, c->rp, la));
+        rc = enqueue_layers(c, a, ROPE_LOSS_DEPTH, n_shared, c->fp);
+        if (rc) return rc;
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers;
     }
     a.table = c->d_table;

@@ -81,6 +81,11 @@ struct RasterArgs {
     const int32_t *cand_of_row;           // MODE_LAYER: layer -> representative candidate; else nullptr
     const int32_t *layer_of;              // candidate -> layer, nullptr when layers are not in use
     const int32_t *layer_rep;             // layer -> representative candidate (with layer_of)
+    // MODE_LAYER, second level: each row's tile is merged (min) with the tile of its parent row of an earlier
+    // MODE_LAYER launch (links shared even more widely: links 0-1 per distinct q0) before it is stored and summed
+    const uint32_t *base_layers;
+    const int32_t *base_of_row;           // row -> parent row
+    const int32_t *base_rep;              // parent row -> its candidate: a parent tile exists only where that candidate's mask_lo says so
     uint32_t *layers;                     // n_layers x n_tiles x (TILE_W*TILE_H) keys
     uint64_t *layer_sums;                 // n_layers x n_tiles x ROPE_SUM_WORDS: loss sums of the layer alone
     const uint64_t *tq; const float *t32; const uint64_t *empty_sums;

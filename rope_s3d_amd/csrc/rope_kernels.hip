@@ -974,6 +974,19 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 
     if (MODE == MODE_LAYER) {
         const size_t slot = (size_t)blockIdx.y * (fp.tiles_x * fp.tiles_y) + tile_id;
+        // the parent launch skipped the tiles its own candidate's shared links do not touch: nothing to merge there
+        const int prow = ra.base_layers ? ra.base_of_row[blockIdx.y] : 0;
+        const bool have_base = ra.base_layers && ((ra.mask_lo[(size_t)ra.base_rep[prow] * ra.mask_words + (tile_id >> 5)] >> (tile_id & 31)) & 1u);
+        if (have_base) {
+            const uint4 *b4 = reinterpret_cast<const uint4 *>(ra.base_layers + ((size_t)prow * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H));
+            for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) {
+                uint4 k = reinterpret_cast<uint4 *>(tile)[i];
+                const uint4 b = b4[i];
+                k.x = min(k.x, b.x); k.y = min(k.y, b.y); k.z = min(k.z, b.z); k.w = min(k.w, b.w);
+                reinterpret_cast<uint4 *>(tile)[i] = k;
+            }
+            __syncthreads();
+        }
         uint4 *dst = reinterpret_cast<uint4 *>(ra.layers + slot * (TILE_W * TILE_H));
         for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS) dst[i] = reinterpret_cast<const uint4 *>(tile)[i];
         // loss sums of the layer alone (relative to "nothing rendered"): every candidate on this layer starts from them

@@ -60,12 +60,26 @@ def test_full_grid_layers_equal_direct_rendering(full):
     cand = helpers.slu_grid(rb.joint_limits, 16)
     for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL):
         _, sums_a, bi_a, _ = e.eval(cand, 6, loss, want_sums=True)
+        for flag in (128, 2048):                       # no shared layers at all; layers without the second level (per q0)
+            e.debug_skip(flag)
+            try:
+                _, sums_b, bi_b, _ = e.eval(cand, 6, loss, want_sums=True)
+            finally:
+                e.debug_skip(0)
+            assert np.array_equal(sums_a, sums_b) and bi_a == bi_b, (loss, flag)
+    # a grid whose first joint takes few values and the second many: parents with many layers each, and n_render = 4
+    grid = np.zeros((3 * 40 * 4, 6))
+    q0, q1, q2 = np.meshgrid(np.linspace(-.5, 1.2, 3), np.linspace(-.9, 1.4, 40), np.linspace(-.6, 2.0, 4), indexing='ij')
+    grid[:, 0], grid[:, 1], grid[:, 2] = q0.ravel(), q1.ravel(), q2.ravel()
+    grid = grid[np.random.default_rng(5).permutation(len(grid))]
+    for n in (4, 6):
+        _, sums_a, bi_a, _ = e.eval(grid, n, eng.LOSS_FULL, want_sums=True)
         e.debug_skip(128)
         try:
-            _, sums_b, bi_b, _ = e.eval(cand, 6, loss, want_sums=True)
+            _, sums_b, bi_b, _ = e.eval(grid, n, eng.LOSS_FULL, want_sums=True)
         finally:
             e.debug_skip(0)
-        assert np.array_equal(sums_a, sums_b) and bi_a == bi_b
+        assert np.array_equal(sums_a, sums_b) and bi_a == bi_b, n
 
 
 def test_mismatch_counts_match_rendered_images(full):
