@@ -52,7 +52,7 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample):
+def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None):
     """The CPU oracle (C restatement of the reference path) on this host's cores, bounded sample."""
     from oracle import oracle as orc
     # the GPU box exposes every host core but a 1-GPU job's share is 16 (gpurun process guard)
@@ -62,14 +62,19 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample):
     sample = np.ascontiguousarray(cand[:n_sample])
     o.eval(sample[:threads], orc.LOSS_DEPTH, 6, tq, threads=threads)          # warm-up
     t0 = time.perf_counter()
-    o.eval(sample, orc.LOSS_DEPTH, 6, tq, threads=threads)
+    cpu_err = o.eval(sample, orc.LOSS_DEPTH, 6, tq, threads=threads)
     dt = time.perf_counter() - t0
     one = sample[:max(threads * 4, 64)]
     t1 = time.perf_counter()
     o.eval(one, orc.LOSS_DEPTH, 6, tq, threads=1)
     dt1 = time.perf_counter() - t1
+    parity = None
+    if gpu_err is not None:       # the same rows as the GPU scored them in the timed passes: the checker's other job
+        g = np.asarray(gpu_err[:len(sample)], np.float64)
+        parity = {"rows": int(len(sample)), "identical_bits": bool(np.array_equal(g.view(np.uint64), cpu_err.view(np.uint64))),
+                  "max_abs_diff": float(np.nanmax(np.abs(g - cpu_err))) if len(sample) else 0.0}
     return {"value": len(sample) / dt, "unit": "poses/s", "cores": threads, "kind": "port",
-            "single_thread_value": len(one) / dt1,
+            "single_thread_value": len(one) / dt1, "gpu_errors_vs_port": parity,
             "sample": f"first {len(sample)} of the {len(cand)} grid candidates, {threads} threads over candidates, "
                       f"{dt:.2f} s wall; single thread: first {len(one)} candidates, {dt1:.2f} s"}
 
@@ -212,7 +217,8 @@ def main():
                                               "pass_total": kern['total']}},
         }
         if not args.no_cpu_baseline and world == 1:           # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C))
+            gpu_err = e.download(want_err=True)[0]                 # errors of the last timed pass, outside the timed region
+            out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C), gpu_err)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
