@@ -178,6 +178,23 @@ def predict_reference(o: orc.Oracle, tgt_depth, tgt_blue, link_names, link_blue,
                         err_history[0] = pred_min_err
                     history[1:] = history[:-1]
                     history[0] = angles
+            elif kind == 'tsweep':                     # predict.py:340-373; not in the default lists
+                _, n, div, letters, rng = st
+                t_full = np.ascontiguousarray(tgt_depth, np.float32)       # the whole target, both sides sqrt-ed
+                for idx in np.where(_mask(letters))[0]:
+                    lo, hi = angles.copy(), angles.copy()
+                    if rng is None:
+                        lo[idx], hi[idx] = lim[idx, 0], lim[idx, 1]
+                    else:
+                        lo[idx] = max(lo[idx] - rng, lim[idx, 0])
+                        hi[idx] = min(hi[idx] + rng, lim[idx, 1])
+                    space = np.linspace(lo, hi, div)
+                    score = np.empty(div)
+                    for i, a_ in enumerate(space):
+                        key = o.raster_key(a_, n)
+                        score[i] = o.finalize(o.sums(key, orc.LOSS_TSWEEP, n, None, t_full), orc.LOSS_TSWEEP, n, n_pix, flags)
+                    count[0] += div
+                    angles = space[int(np.argmin(score))]               # mean * -std: the `*-` of predict.py:367
             else:
                 raise ValueError(kind)
             trace.append((kind, np.array(angles, dtype=float)))

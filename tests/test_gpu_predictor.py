@@ -144,3 +144,35 @@ def test_predict_dataset_two_ranks_shard_and_gather(tmp_path):
                          cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert two.returncode == 0, two.stdout + two.stderr
     assert np.array_equal(np.load(tmp_path / 'predictions_synth4r.npy'), single)      # frames are independent: same bits
+
+
+def test_tensor_sweep_stage_matches_reference(synth):
+    """TensorSweep (predict.py:340-373) is in no default stage list; run it inside a custom list on both sides."""
+    from rope_s3d_amd.prediction.stages import Descent, Lookup, SFlip, TensorSweep
+    p = synth.predictor
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    q_true = np.random.default_rng(77).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    synth.renderer.setJointAngles(q_true)
+    color, depth = synth.renderer.render()
+    stages = [Lookup(), TensorSweep(6, 12, 'U'), SFlip(4), TensorSweep(4, 9, 'SL', 0.2), Descent(6, 5, 'SLU', early_stop=.0075)]
+    orig = p._setStages
+    p._setStages = lambda: setattr(p, 'stages', stages)
+    try:
+        got = p.run(color, depth)
+    finally:
+        p._setStages = orig
+    intr, PV = helpers.camera('640_480_color', ds=4, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+    tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+    names = rb.link_names
+    link_blue = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    ref_stages = [('lookup',), ('tsweep', 6, 12, 'U', None), ('sflip', 4), ('tsweep', 4, 9, 'SL', 0.2),
+                  ('descent', 6, 5, 'SLU', [None] * 6, 0.5, 0.0075)]
+    want, trace, _ = predictor_ref.predict_reference(o, tgt_depth, tgt_blue, names, link_blue, lim, DEFAULT_CAMERA_POSE,
+                                                     helpers.slu_grid(lim, 4), p.lookup_crop, 'SLU', stages=ref_stages)
+    assert len(trace) == len(p.trace)
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
