@@ -176,3 +176,29 @@ def test_tensor_sweep_stage_matches_reference(synth):
     for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
         assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('seed', [5, 6])
+def test_sl_stage_list_trace_matches_reference(seed):
+    """do_angles='SL' (stages.py:138-150): Lookup, SFlip, two interpolative sweeps, SFlip — and the 'SL' lookup grid."""
+    from rope_s3d_amd import SyntheticPredictor
+    sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '640_480_color', 4, 'SL', noise=False, seed=3, lookup_divisions=6)
+    p = sp.predictor
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    q_true = np.random.default_rng(seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 0, 0, 0, 0])
+    sp.renderer.setJointAngles(q_true)
+    color, depth = sp.renderer.render()
+    got = p.run(color, depth)
+    intr, PV = helpers.camera('640_480_color', ds=4, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+    tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+    names = rb.link_names
+    link_blue = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    want, trace, _ = predictor_ref.predict_reference(o, tgt_depth, tgt_blue, names, link_blue, lim, DEFAULT_CAMERA_POSE,
+                                                     p.lookup_angles, p.lookup_crop, 'SL')
+    assert [k for k, _ in trace] == ['lookup', 'sflip', 'isweep', 'isweep', 'sflip'] and len(trace) == len(p.trace)
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
