@@ -202,3 +202,34 @@ def test_sl_stage_list_trace_matches_reference(seed):
     for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
         assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
     assert np.array_equal(got, want)
+
+
+def test_camera_pose_change_between_frames(synth):
+    """run(..., camera_pose) with a new pose rebuilds crops and the lookup table (predict.py:105-117,127-130); the trace
+    under the new camera matches the restatement, and going back to the first pose reproduces the first answer."""
+    p = synth.predictor
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    q_true = np.random.default_rng(31).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    synth.renderer.setCameraPose(DEFAULT_CAMERA_POSE)
+    synth.renderer.setJointAngles(q_true)
+    color0, depth0 = synth.renderer.render()
+    first = p.run(color0, depth0, DEFAULT_CAMERA_POSE)
+    pose = np.array([0.25, -1.4, 0.9, 0.0, -0.12, 0.2])
+    synth.renderer.setCameraPose(pose)
+    color, depth = synth.renderer.render()
+    synth.renderer.setCameraPose(DEFAULT_CAMERA_POSE)
+    got = p.run(color, depth, pose)
+    assert np.array_equal(p.camera_pose, pose)
+    intr, PV = helpers.camera('640_480_color', ds=4, pose=pose, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+    tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+    names = rb.link_names
+    link_blue = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    want, trace, _ = predictor_ref.predict_reference(o, tgt_depth, tgt_blue, names, link_blue, lim, pose,
+                                                     helpers.slu_grid(lim, 4), p.lookup_crop, 'SLU')
+    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+        assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    assert np.array_equal(got, want)
+    assert np.array_equal(p.run(color0, depth0, DEFAULT_CAMERA_POSE), first)
