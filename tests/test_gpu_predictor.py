@@ -233,3 +233,19 @@ def test_camera_pose_change_between_frames(synth):
         assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
     assert np.array_equal(got, want)
     assert np.array_equal(p.run(color0, depth0, DEFAULT_CAMERA_POSE), first)
+
+
+def test_synth_cli_with_noise_then_plot_errors(tmp_path, monkeypatch, capsys):
+    """synth.py (render -> holes noise -> predict, partial saves) and plot_errors.py on its result file."""
+    import argparse
+    import importlib
+    monkeypatch.chdir(tmp_path)
+    sy = importlib.import_module('synth')
+    sy.run(argparse.Namespace(dataset='none', num=5, file='synth_test', noise=True, ds_factor=8, angs='SLU', intrinsics='1280_720_color'))
+    res = np.load(tmp_path / 'synth_test.npy')
+    assert res.shape == (2, 5, 6) and np.isfinite(res).all()
+    assert np.abs(res[1] - res[0])[:, :3].mean() < 0.25            # holes in the depth map: loose sanity bound
+    pe = importlib.import_module('plot_errors')
+    pe.run(argparse.Namespace(file=str(tmp_path / 'synth_test'), sort_by='S', angs='SLU', dataset=None))
+    out = capsys.readouterr().out
+    assert out.count('Err Stats (deg)') >= 2 and 'Err Stats (cm)' in out
