@@ -249,3 +249,38 @@ def test_synth_cli_with_noise_then_plot_errors(tmp_path, monkeypatch, capsys):
     pe.run(argparse.Namespace(file=str(tmp_path / 'synth_test'), sort_by='S', angs='SLU', dataset=None))
     out = capsys.readouterr().out
     assert out.count('Err Stats (deg)') >= 2 and 'Err Stats (cm)' in out
+
+
+def test_other_robot_as_active_urdf():
+    """Paths.set('URDF', ...) switches the active robot (the reference edits data/paths.json): motoman mh50, camera
+    pulled back, 1280x720 / 8 — the whole Predictor trace against the restatement built from the same URDF."""
+    from rope_s3d_amd import SyntheticPredictor
+    from rope_s3d_amd.config import Paths
+    from rope_s3d_amd.urdf import URDFReader
+    urdf = 'urdfs/motoman_mh50_support/urdf/mh50.urdf'
+    old = Paths().URDF
+    Paths().set('URDF', urdf)
+    try:
+        pose = [0, -4.0, 1.5, 0, 0, 0]
+        sp = SyntheticPredictor(pose, '1280_720_color', 8, 'SLU', noise=False, seed=5, lookup_divisions=4)
+        p = sp.predictor
+        assert URDFReader().name == 'mh50' and p.renderer.robot.link_names[1] == URDFReader().mesh_names[1]
+        rb = helpers.robot(urdf)
+        lim = URDFReader().joint_limits
+        q_true = np.random.default_rng(9).uniform(lim[:, 0] * .4, lim[:, 1] * .4) * np.array([1, 1, 1, 0, 0, 0])
+        sp.renderer.setJointAngles(q_true)
+        color, depth = sp.renderer.render()
+        got = p.run(color, depth)
+        intr, PV = helpers.camera('1280_720_color', ds=8, pose=pose, as_predictor=True)
+        o = helpers.make_oracle(rb, intr, PV)
+        tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+        tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+        names = rb.link_names
+        link_blue = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+        want, trace, _ = predictor_ref.predict_reference(o, tgt_depth, tgt_blue, names, link_blue, lim, pose,
+                                                         p.lookup_angles, p.lookup_crop, 'SLU')
+        for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+            assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+        assert np.array_equal(got, want)
+    finally:
+        Paths().set('URDF', old)
