@@ -181,7 +181,7 @@ __device__ static inline void acc_sq(uint64_t *s, uint64_t dq)
 template <int LOSS, bool NEG = false>
 __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t t /* tq[pix] */,
                                           const float ta /* t32[pix] */, const uint64_t *__restrict__ tl, size_t plane,
-                                          float c_num, float c_sum, float c_dif, uint64_t *s)
+                                          float c_num, float c_sum, float c_dif, uint64_t *s, uint64_t *pk = nullptr)
 {
     const bool empty = (key == KEY_EMPTY);
     float z = empty ? 0.0f : linear_depth(key >> 8, c_num, c_sum, c_dif);
@@ -208,8 +208,9 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
                 if (!M && !R && !(tll & 0x7FFFFFFFFFull)) continue;
                 const uint64_t a = tll & 0x7FFFFFFFFFull, b = R ? zq : 0;
                 const uint64_t dl = a > b ? a - b : b - a;
-                acc<NEG>(s[SUM_LINK0 + 3 * l], (uint64_t)(M != R));
-                if (dl) { acc<NEG>(s[SUM_LINK0 + 3 * l + 1], 1); acc<NEG>(s[SUM_LINK0 + 3 * l + 2], sqrt_q32(dl)); }
+                pk[NEG ? 1 : 0] += (uint64_t)(M != R) << (10 * l);          // six 10-bit fields (see ROPE_LOSS_FULL below)
+                pk[NEG ? 3 : 2] += (uint64_t)(dl != 0) << (10 * l);
+                if (dl) acc<NEG>(s[SUM_LINK0 + 3 * l + 2], sqrt_q32(dl));
             }
         }
         return;
@@ -228,8 +229,11 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
                 const bool M = (mask >> l) & 1, R = (id == l);
                 const uint64_t a = M ? T : 0, b = R ? zq : 0;
                 const uint64_t dl = a > b ? a - b : b - a;
-                acc<NEG>(s[SUM_LINK0 + 3 * l], (uint64_t)(M != R));
-                if (dl) { acc<NEG>(s[SUM_LINK0 + 3 * l + 1], 1); acc<NEG>(s[SUM_LINK0 + 3 * l + 2], dl); }
+                // the two counts of every link live as 12-bit fields of packed words (a thread meets at most 16 samples):
+                // pk[0]/pk[1] mask mismatches added / subtracted, pk[2]/pk[3] non-zero link differences added / subtracted
+                pk[NEG ? 1 : 0] += (uint64_t)(M != R) << (12 * (l - 1));
+                pk[NEG ? 3 : 2] += (uint64_t)(dl != 0) << (12 * (l - 1));
+                acc<NEG>(s[SUM_LINK0 + 3 * l + 2], dl);
             }
         }
     }
@@ -258,6 +262,7 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
     uint64_t s[ROPE_SUM_WORDS];
 #pragma unroll
     for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
+    uint64_t pk[4] = {0, 0, 0, 0};                      // ROPE_LOSS_FULL: packed per-link counts (score_pixel)
     if (DELTA) {
         // Only samples whose key differs from the base tile (the shared layer, or nothing) change the sums, and only
         // the rectangle this launch could draw into can hold any.  The z-test is a minimum over keys, so the tile
@@ -300,8 +305,8 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
             for (int j = 0; j < 4; j++) {
                 if (keys[j] == bas[j]) continue;
                 if (!pixel_active(row, colg + j, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-                score_pixel<LOSS, false>(keys[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
-                score_pixel<LOSS, true>(bas[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
+                score_pixel<LOSS, false>(keys[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk);
+                score_pixel<LOSS, true>(bas[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk);
             }
         }
     } else {
@@ -310,7 +315,21 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
             if (!pixel_active(row, col, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
             const size_t pix = (size_t)row * fp.W + col;
             constexpr bool USE_F = (LOSS == ROPE_LOSS_LOOKUP || LOSS == ROPE_LOSS_TSWEEP);
-            score_pixel<LOSS>(KEY_EMPTY, pix, n_render, USE_F ? 0ull : tq[pix], USE_F ? t32[pix] : 0.0f, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s);
+            score_pixel<LOSS>(KEY_EMPTY, pix, n_render, USE_F ? 0ull : tq[pix], USE_F ? t32[pix] : 0.0f, tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk);
+        }
+    }
+    if (LOSS == ROPE_LOSS_CAMFULL) {
+#pragma unroll
+        for (int l = 0; l < ROPE_MAX_LINKS; l++) {
+            s[SUM_LINK0 + 3 * l] = ((pk[0] >> (10 * l)) & 0x3FFull) - ((pk[1] >> (10 * l)) & 0x3FFull);
+            s[SUM_LINK0 + 3 * l + 1] = ((pk[2] >> (10 * l)) & 0x3FFull) - ((pk[3] >> (10 * l)) & 0x3FFull);
+        }
+    }
+    if (LOSS == ROPE_LOSS_FULL) {
+#pragma unroll
+        for (int l = 1; l < ROPE_MAX_LINKS; l++) {
+            s[SUM_LINK0 + 3 * l] = ((pk[0] >> (12 * (l - 1))) & 0xFFFull) - ((pk[1] >> (12 * (l - 1))) & 0xFFFull);
+            s[SUM_LINK0 + 3 * l + 1] = ((pk[2] >> (12 * (l - 1))) & 0xFFFull) - ((pk[3] >> (12 * (l - 1))) & 0xFFFull);
         }
     }
     // one LDS atomic per word and wave: the partial sums (modulo 2^64) are added up across the lanes first, and
