@@ -20,7 +20,7 @@ namespace rope {
 #define ROPE_MIN_WAVES_PER_SIMD 6
 #endif
 #ifndef ROPE_MIN_WAVES_FULL
-#define ROPE_MIN_WAVES_FULL 6               // measured: 6 waves with loss-pass spills beat 4 without (7.7 vs 8.4 ms)
+#define ROPE_MIN_WAVES_FULL 6               // the link counts are packed fields (score_pixel): fits 80 VGPRs without spills
 #endif
 constexpr int TILE_W = ROPE_TILE_W;
 constexpr int TILE_H = ROPE_TILE_H;
