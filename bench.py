@@ -52,7 +52,7 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None):
+def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None, loss=0, flags=None):
     """The CPU oracle (C restatement of the reference path) on this host's cores, bounded sample."""
     from oracle import oracle as orc
     # the GPU box exposes every host core but a 1-GPU job's share is 16 (gpurun process guard)
@@ -60,13 +60,13 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None)
     o = orc.Oracle(robot.verts, robot.faces, robot.vtx_off, robot.tri_off, robot.joint_fixed, robot.joint_axes,
                    PV, W, H, znear, zfar)
     sample = np.ascontiguousarray(cand[:n_sample])
-    o.eval(sample[:threads], orc.LOSS_DEPTH, 6, tq, threads=threads)          # warm-up
+    o.eval(sample[:threads], loss, 6, tq, link_flags=flags, threads=threads)          # warm-up
     t0 = time.perf_counter()
-    cpu_err = o.eval(sample, orc.LOSS_DEPTH, 6, tq, threads=threads)
+    cpu_err = o.eval(sample, loss, 6, tq, link_flags=flags, threads=threads)
     dt = time.perf_counter() - t0
     one = sample[:max(threads * 4, 64)]
     t1 = time.perf_counter()
-    o.eval(one, orc.LOSS_DEPTH, 6, tq, threads=1)
+    o.eval(one, loss, 6, tq, link_flags=flags, threads=1)
     dt1 = time.perf_counter() - t1
     parity = None
     if gpu_err is not None:       # the same rows as the GPU scored them in the timed passes: the checker's other job
@@ -90,6 +90,9 @@ def main():
                          "mh50, 1280x720, 32^3 candidates")
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--loss', default='depth', choices=['depth', 'full'],
+                    help="depth = the metric's loss (last term of Predictor._error); full = the whole _error with the link masks "
+                         "(SURVEY §8d: +2*W*H bytes per candidate for the id image)")
     ap.add_argument('--split-candidates', action='store_true',
                     help="strong scaling (SURVEY §8e, optional): ONE frame, its candidates split over the ranks, all-gather of "
                          "(best error, best index) and a global argmin; default is one frame per rank (weak scaling)")
@@ -143,8 +146,18 @@ def main():
     rng = np.random.default_rng(7919 + (0 if args.split_candidates else rank))
     q_true = rng.uniform(robot.joint_limits[:, 0], robot.joint_limits[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
     depth, ids = e.render(q_true, 6)
-    tq = eng.pack_target(depth.astype(np.float64))
-    e.set_target(tq, None, np.zeros(8, np.uint8))
+    loss = eng.LOSS_FULL if args.loss == 'full' else eng.LOSS_DEPTH
+    bits, flags = None, np.zeros(8, np.uint8)
+    if args.loss == 'full':                       # link masks of the synthetic frame, as _loadSynthetic reads them
+        bits = np.zeros(ids.shape, np.uint64)
+        for l in range(6):
+            m = (ids == l) | ((ids == 255) if l == 0 else False)      # base_link's colour 0 equals the background's
+            bits |= m.astype(np.uint64) << np.uint64(l)
+            flags[l] = 1 | (2 if np.count_nonzero(m & (depth != 0)) > .05 * np.count_nonzero(m) else 0)
+        b_cand += 2 * W * H
+        label = label.replace('depth-only loss', 'full _error loss (link masks + depth)')
+    tq = eng.pack_target(depth.astype(np.float64), bits)
+    e.set_target(tq, None, flags)
 
     cand = slu_grid(robot.joint_limits, args.grid)
     C_total = len(cand)
@@ -163,7 +176,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        e.eval_resident(6, eng.LOSS_DEPTH)
+        e.eval_resident(6, loss)
     e.sync()
 
     best = torch.zeros(8 if args.split_candidates else 6, dtype=torch.float64, device=coll_dev)
@@ -173,7 +186,7 @@ def main():
     t0 = time.perf_counter()
     # the K timed steps run inside rope_profile_eval, which brackets every kernel with HIP events
     # on the engine's own stream (torch.cuda.Event would only see torch's current stream)
-    kern = e.profile_eval(6, eng.LOSS_DEPTH, None, reps=args.steps)
+    kern = e.profile_eval(6, loss, None, reps=args.steps)
     _, _, bi, be = e.download(want_err=False)
     if args.split_candidates:
         best.copy_(torch.from_numpy(np.concatenate([cand[bi], [be, first + bi]])))
@@ -209,8 +222,8 @@ def main():
                        "parallelism": f"candidates of one frame /{world}" if args.split_candidates else f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "raster_score_kernel<DEPTH,SCORE> (+ its <DEPTH,LAYER> launch: links 0-2 once per distinct (S,L))",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic() if (args.loss == 'depth' and args.workload == 'cfg1') else None,
+                         "kernel": "raster_score_kernel<%s,SCORE> (+ its <%s,LAYER> launches: links 0-2 once per distinct (S,L))" % ((args.loss.upper(),) * 2),
                          "kernel_ms": kern['raster'], "score_launch_ms": kern['score'], "layer_launch_ms": kern['layer'],
                          "bytes_per_candidate": b_cand, "candidates_per_launch": C,
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
@@ -218,7 +231,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:           # reported at N=1 only
             gpu_err = e.download(want_err=True)[0]                 # errors of the last timed pass, outside the timed region
-            out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C), gpu_err)
+            out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C), gpu_err, loss, flags)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
