@@ -44,3 +44,4 @@ DEFAULT_RENDER_COLORS = render_colors(MAX_LINKS)
 # channel-0 value per rendered link id; 255 marks background in the engine's id image
 LINK_BLUE = np.array([c[0] for c in DEFAULT_RENDER_COLORS], dtype=np.uint8)
 BACKGROUND_ID = 255
+VIDEO_FPS = 15      # default preview video frames per second (constants.py:58)

@@ -13,7 +13,7 @@ from typing import Callable, Optional
 
 import numpy as np
 
-from ..constants import DEFAULT_CAMERA_POSE, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
+from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
 from ..crop import Crop
 from ..engine import LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, pack_target
 from ..imgproc import dilate, erode, resize_linear
@@ -101,9 +101,11 @@ class Predictor:
         lookup_table_budget  bytes of HBM the stored lookup table may take (default 32 GiB); larger grids are
                           rendered and scored on the fly every frame instead
         """
-        if preview:
-            raise NotImplementedError("preview needs an OpenCV window (ProjectionViz, predict.py:517-602): out of scope")
         self.ds_factor, self.preview = ds_factor, preview
+        if preview:                       # headless: frames go to .viz.frame and, with save_to, an uncompressed AVI
+            from .viz import ProjectionViz
+            self.viz = ProjectionViz(save_to)
+            self.SPECULATE = 1            # show exactly the renders the reference's serial descent would look at
         self.do_angles = do_angles.upper()
         self.min_ang_inc, self.history_length = np.asarray(min_angle_inc, dtype=float), HISTORY_LENGTH
 
@@ -207,8 +209,11 @@ class Predictor:
             raise NotImplementedError(
                 "no segmenter: pass segmenter=callable(colour)->{'class_ids','scores','masks'} (the Mask R-CNN "
                 "stage on PyTorch-ROCm is SURVEY §8f rank 1), or color_dict for synthetic input")
-        r = self.seg(self._downsample(target_color, self.ds_factor))
+        small = self._downsample(target_color, self.ds_factor)
+        r = self.seg(small)
         seg = self._reorganize_by_link(r)
+        if self.preview:                  # pixellib hands back the frame with its masks painted on (predict.py:416)
+            self._preview_links = self._paint_links(small, seg)
         lookup_depth = segment_targets(seg, target_depth, self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED])
         self._upload_target(target_depth, lookup_depth, {k: v['mask'] for k, v in seg.items()})
         return target_depth
@@ -216,6 +221,7 @@ class Predictor:
     def _loadSynthetic(self, target_color, target_depth):
         """Synthetic path: link masks are read off channel 0 of the colour render (predict.py:445-469)."""
         target_color = self._downsample(target_color, self.ds_factor)
+        self._preview_links = target_color                    # `output` of predict.py:469
         blue = target_color[..., 0]
         hit = np.zeros(target_depth.shape, bool)            # the reference sums the comparisons and casts to bool (predict.py:449-454)
         for k in self.color_dict:
@@ -236,7 +242,27 @@ class Predictor:
         cand = np.asarray(candidates, dtype=np.float64).reshape(-1, 6)
         err, _, _, _ = self.engine.eval(cand, n_render, LOSS_FULL)
         self.evaluations += len(cand)
+        if self.preview:
+            self._show(n_render, cand)
         return [float(e) for e in err]
+
+    def _show(self, n_render: int, cand: np.ndarray):
+        """preview_if_applicable (predict.py:153-157): one preview frame per evaluated pose."""
+        self.renderer.setMaxParts(n_render)
+        for q in cand:
+            self.renderer.setJointAngles(q)
+            color, depth = self.renderer.render()
+            self.viz.loadRenderedColor(color)
+            self.viz.loadRenderedDepth(depth)
+            self.viz.show()
+
+    def _paint_links(self, color: np.ndarray, seg: dict) -> np.ndarray:
+        out = color.astype(np.float64)
+        for name, d in seg.items():
+            if name in self.link_names:
+                c = np.array(DEFAULT_RENDER_COLORS[self.link_names.index(name)], np.float64)
+                out[d['mask']] = out[d['mask']] * .5 + c * .5
+        return np.rint(out).astype(np.uint8)
 
     # ------------------------------------------------------------------ the state machine
     def run(self, target_color, target_depth, camera_pose=None):
@@ -250,6 +276,10 @@ class Predictor:
             self._loadSynthetic(target_color, target_depth)
         else:
             self._segmentLoad(target_color, target_depth)
+        if self.preview:
+            self.viz.loadTargetColor(target_color)
+            self.viz.loadTargetDepth(target_depth)
+            self.viz.loadSegmentedLinks(self._preview_links)
 
         limits = self.u_reader.joint_limits
         lr = np.ones(6) * 0.1
@@ -367,6 +397,9 @@ class Predictor:
             rows.append(temp.copy())
         if not in_limits or close_to_limits:
             endpoint = temp.copy()
+            if self.preview:                                        # the reference renders the lower limit too, only to
+                endpoint[0] = limits[0][0]                          # overwrite its error (below); shown, never compared
+                rows.append(endpoint.copy())
             endpoint[0] = limits[0][1]
             rows.append(endpoint)
         errs = self._errors(n, np.array(rows))
@@ -438,6 +471,8 @@ class Predictor:
                 _, _, space = self._sweep_space(stage, angles, idx, limits)
                 _, _, best, _ = self.engine.eval(space, n, LOSS_TSWEEP)
                 self.evaluations += len(space)
+                if self.preview:
+                    self._show(n, space)
                 angles = space[best]
         finally:
             self.engine.set_target(self._tq, self._lookup_depth_f32, self._flags)

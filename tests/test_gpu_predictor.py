@@ -284,3 +284,39 @@ def test_other_robot_as_active_urdf():
         assert np.array_equal(got, want)
     finally:
         Paths().set('URDF', old)
+
+
+def test_preview_shows_the_reference_render_sequence(synth, tmp_path):
+    """preview=True (ProjectionViz, predict.py:153-157,510-602): same angles as without it, one preview frame per
+    pose the reference's serial loop renders (== the oracle's evaluation count minus the lookup), and a video file
+    holding exactly those frames."""
+    from rope_s3d_amd import Predictor
+    p0 = synth.predictor
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    q_true = np.random.default_rng(7919).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    synth.renderer.setJointAngles(q_true)
+    color, depth = synth.renderer.render()
+    want = p0.run(color, depth)
+
+    video = tmp_path / 'preview.avi'
+    p = Predictor(DEFAULT_CAMERA_POSE, 4, True, str(video), 'SLU', base_intrin='640_480_color',
+                  color_dict=p0.color_dict, lookup_divisions=4)
+    got = p.run(color, depth)
+    assert np.array_equal(got, want)
+
+    intr, PV = helpers.camera('640_480_color', ds=4, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+    tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+    names = rb.link_names
+    _, _, n_eval = predictor_ref.predict_reference(
+        o, tgt_depth, tgt_blue, names, {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}, lim, DEFAULT_CAMERA_POSE,
+        helpers.slu_grid(lim, 4), p.lookup_crop, 'SLU')
+    assert p.viz.shown == n_eval - len(p.lookup_angles)             # the lookup stage renders nothing per frame
+    frame = p.viz.frame
+    assert frame.shape == (720, 1280, 3) and frame[:360, 640:].any() and frame[360:, :640].any()
+    p.viz.close()
+    size = os.path.getsize(video)
+    per_frame = 8 + 1280 * 720 * 3
+    assert (size - p.viz.shown * per_frame) < 4096 and size > p.viz.shown * per_frame

@@ -290,3 +290,40 @@ def test_analysis_tables_and_joint_distance(tmp_path, capsys):
     pe.run(argparse.Namespace(file=str(tmp_path / 'synth_test'), sort_by='S', angs='SLU', dataset=None))
     out = capsys.readouterr().out
     assert 'Err Stats (deg)' in out and 'Err Stats (cm)' in out
+
+
+def test_projection_viz_frame_and_avi(tmp_path):
+    """Headless ProjectionViz (predict.py:510-602): quadrant layout, the grey 'both empty' rule, and a well-formed
+    uncompressed AVI whose header counts the frames written."""
+    import struct
+    from rope_s3d_amd.prediction.viz import ProjectionViz, color_array, resize_nearest
+    rng = np.random.default_rng(3)
+    h, w = 90, 160
+    color = rng.integers(0, 255, (720, 1280, 3), dtype=np.uint8)
+    tgt = np.zeros((h, w)); tgt[20:60, 30:100] = rng.uniform(1, 2, (40, 70))
+    rend = np.zeros((h, w), np.float32); rend[30:70, 50:120] = 1.5
+    rcol = np.zeros((h, w, 3), np.uint8); rcol[30:70, 50:120] = (85, 0, 85)
+    path = tmp_path / 'v.avi'
+    v = ProjectionViz(str(path), fps=15, resolution=(640, 360))
+    v.loadTargetColor(color); v.loadTargetDepth(tgt); v.loadSegmentedLinks(rcol)
+    for _ in range(3):
+        v.loadRenderedColor(rcol); v.loadRenderedDepth(rend); v.show()
+    f = v.frame
+    assert f.shape == (360, 640, 3) and v.shown == 3
+    assert (f[179:182] == 255).all() and (f[:, 319:322] == 255).all()
+    q = f[180:, 320:]                                        # render depth vs input depth, nearest 160x90 -> 320x180
+    assert tuple(q[170, 10]) == (55, 55, 55)                 # nothing rendered, nothing measured
+    assert tuple(q[2 * 25 + 5, 2 * 40 + 5]) == (0, 0, 0)     # measured but not rendered: difference zeroed, drawn black
+    assert q[2 * 45 + 5, 2 * 75 + 5].any()                   # both: colour-mapped difference
+    assert np.array_equal(resize_nearest(np.arange(12).reshape(3, 4), 8, 6)[::2, ::2], np.arange(12).reshape(3, 4))
+    c = color_array(np.arange(11.0).reshape(1, 11))
+    assert tuple(c[0, 0]) == (0, 0, 0) and c[0, 3, 0] > c[0, 3, 2] and c[0, 9, 2] > c[0, 9, 0]     # blue end -> red end (BGR)
+    v.close()
+    raw = path.read_bytes()
+    assert raw[:4] == b'RIFF' and raw[8:12] == b'AVI ' and struct.unpack('<I', raw[4:8])[0] == len(raw) - 8
+    avih = raw.index(b'avih')
+    assert struct.unpack('<I', raw[avih + 8 + 16:avih + 8 + 20])[0] == 3          # dwTotalFrames
+    movi = raw.index(b'movi')
+    assert raw[movi + 4:movi + 8] == b'00db' and len(raw) - (movi + 4) == 3 * (8 + 640 * 360 * 3)
+    first = np.frombuffer(raw[movi + 12:movi + 12 + 640 * 360 * 3], np.uint8).reshape(360, 640, 3)[::-1]
+    assert np.array_equal(first[180:, 320:], f[180:, 320:])
