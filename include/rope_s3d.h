@@ -124,6 +124,50 @@ int rope_set_frames(rope_ctx *ctx, int n_frames, const double *q, const uint64_t
                     const uint64_t *link_planes);
 int rope_eval_views(rope_ctx *ctx, const double *PV, int K, int n_render, int loss, uint64_t *sums_out);
 
+/* The whole per-frame stage machine on the host, driving device batches through the calls above.
+ * Replaces the stage loop of Predictor.run (predict.py:144-375) for the stages of the reference's 'SL' and 'SLU'
+ * lists (stages.py:128-178); the target must have been set with rope_set_target (full loss masks + lookup plane).
+ * Decisions follow the reference operation for operation, quirks included (SFlip's aliasing and its comparison
+ * outside the endpoint loop, ISweep's stale base error, Descent's error history of the last joint only); the
+ * not-a-knot cubic of interp1d(kind='cubic') (predict.py:310) is solved directly.  TensorSweep is not part of
+ * either list and is not offered here (drive it with rope_eval and ROPE_LOSS_TSWEEP). */
+enum {
+    ROPE_STAGE_LOOKUP = 0,   /* stages.py:16-24   predict.py:165-171 */
+    ROPE_STAGE_DESCENT = 1,  /* stages.py:92-119  predict.py:173-230 */
+    ROPE_STAGE_SFLIP = 2,    /* stages.py:30-41   predict.py:232-281 */
+    ROPE_STAGE_ISWEEP = 3    /* stages.py:50-69   predict.py:283-338 */
+};
+
+typedef struct rope_stage {
+    int32_t kind;
+    int32_t to_render;        /* links drawn: 4 or 6 (Lookup: LOOKUP_NUM_RENDERED) */
+    int32_t count;            /* Descent: iterations; InterpolativeSweep: divisions (>= 4) */
+    uint32_t joints;          /* bit j set: joint j (S=0 .. T=5) takes part */
+    double init_rate[6];      /* Descent: starting step per joint, NaN = keep the running step (None) */
+    double rate_reduction;    /* Descent */
+    double early_stop;        /* Descent */
+    double range;             /* InterpolativeSweep: rad about the current angle, NaN = the whole joint range */
+} rope_stage;
+
+typedef struct rope_predict_args {
+    const rope_stage *stages;
+    int32_t n_stages;
+    int32_t speculate;            /* Descent: joints whose under/over pairs go out as one batch, 1..3 (1 = the
+                                     reference's two renders at a time; the decisions are the same either way) */
+    const double *limits;         /* 6 x 2 joint limits (URDFReader.joint_limits) */
+    const double *camera_pose;    /* 6: x y z + the three angles, as Predictor.camera_pose (SFlip's axis, predict.py:245) */
+    const double *min_ang_inc;    /* 6 (Predictor.min_ang_inc) */
+    const double *lookup_angles;  /* n_lookup x 6 pose grid (lookup.py:56-66 order) */
+    int32_t n_lookup;
+    int32_t use_table;            /* 1: score the table of rope_lookup_build; 0: render and score the grid now */
+    const int32_t *lookup_crop;   /* r0,r1,c0,c1 when use_table == 0 */
+} rope_predict_args;
+
+/*   angles_out  6 doubles
+ *   trace_out   n_stages x 6 doubles, the angles after every stage; may be NULL
+ *   n_evals     candidate poses rendered and scored (lookup rows included); may be NULL */
+int rope_predict(rope_ctx *ctx, const rope_predict_args *args, double *angles_out, double *trace_out, int64_t *n_evals);
+
 /* Device-side per-candidate link matrices of the last eval (C x n_render x 16 float32), for tests. */
 int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);
 

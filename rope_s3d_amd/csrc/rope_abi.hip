@@ -223,6 +223,9 @@ extern "C" void rope_destroy(rope_ctx *c)
 
 extern "C" const char *rope_last_error(rope_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// for the host-side stage machine (rope_predict.cpp), which sees the context only through the C ABI
+void rope_set_error(rope_ctx *c, const std::string &msg) { if (c) c->err = msg; }
+
 extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_meshlets, const float *ml_verts,
                               int n_ml_verts, const uint32_t *ml_tris, int n_ml_tris, const int32_t *link_first,
                               int n_links, const double *joint_fixed, const double *joint_axes)

@@ -1,0 +1,379 @@
+// rope_predict: the per-frame stage machine of Predictor.run (robotpose/prediction/predict.py:144-375) on the host,
+// written against the public C ABI only (rope_eval / rope_lookup_score) — every batch of candidate poses it asks for
+// is rendered and scored on the device; what runs here is the reference's control flow, a few dozen doubles of state.
+//
+// The arithmetic is the reference's numpy/Python arithmetic restated step by step, so that the decisions — and with
+// them the returned angles — are those of rope_s3d_amd/prediction/predict.py and of the sequential oracle
+// (oracle/predictor_ref.py): np.linspace's two formulas, np.mean's left-to-right sums, Python's min/index semantics
+// with NaN, np.isclose.  The one piece that is not a transcription is the cubic of scipy's interp1d(kind='cubic'):
+// the same not-a-knot spline, solved here by Gaussian elimination on its second derivatives.
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rope_s3d.h"
+
+void rope_set_error(rope_ctx *c, const std::string &msg);       // rope_abi.hip
+
+namespace {
+
+using Vec6 = std::array<double, 6>;
+constexpr int HISTORY = 5;                                      // predict.py:30
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+struct State {
+    Vec6 angles{};                                              // predict.py:148
+    Vec6 lr{{0.1, 0.1, 0.1, 0.1, 0.1, 0.1}};                    // predict.py:144, persists across stages
+    double history[HISTORY][6] = {};
+    double err_history[HISTORY] = {};
+};
+
+struct Machine {
+    rope_ctx *c;
+    const rope_predict_args &a;
+    int64_t evals = 0;
+    std::vector<double> err;
+
+    double lim(int j, int side) const { return a.limits[2 * j + side]; }
+
+    // Predictor._error of every row (render_at_pos + _error, predict.py:159-161,475-509)
+    int errors(int n_render, const std::vector<Vec6> &rows)
+    {
+        err.assign(rows.size(), 0.0);
+        if (rows.empty()) return ROPE_OK;
+        evals += (int64_t)rows.size();
+        return rope_eval(c, rows[0].data(), (int)rows.size(), n_render, ROPE_LOSS_FULL, nullptr, err.data(), nullptr, nullptr, nullptr);
+    }
+};
+
+// Python's min(list) / list.index(min(list)): the first element nothing is strictly smaller than (a leading NaN stays)
+int py_argmin(const double *v, int n)
+{
+    int k = 0;
+    for (int i = 1; i < n; i++)
+        if (v[i] < v[k]) k = i;
+    return k;
+}
+
+// np.argmin: the first NaN if there is one
+int np_argmin(const std::vector<double> &v)
+{
+    for (size_t i = 0; i < v.size(); i++)
+        if (std::isnan(v[i])) return (int)i;
+    return py_argmin(v.data(), (int)v.size());
+}
+
+void push_front(double *hist, int n, double v)
+{
+    for (int i = n - 1; i > 0; i--) hist[i] = hist[i - 1];
+    hist[0] = v;
+}
+
+void push_front(double (*hist)[6], const Vec6 &v)
+{
+    for (int i = HISTORY - 1; i > 0; i--)
+        for (int j = 0; j < 6; j++) hist[i][j] = hist[i - 1][j];
+    for (int j = 0; j < 6; j++) hist[0][j] = v[j];
+}
+
+// np.linspace(start, stop, num)[i] for scalar arguments (numpy/_core/function_base.py): i*step + start, unless the
+// step is zero; the last sample is `stop` itself
+double linspace_scalar(double start, double stop, int num, int i)
+{
+    if (i == num - 1) return stop;
+    const double div = (double)(num - 1), delta = stop - start, step = delta / div;
+    return step == 0.0 ? ((double)i / div) * delta + start : (double)i * step + start;
+}
+
+// np.linspace(lo, hi, num) for the six-vectors of a sweep: five of the six steps are zero there, which sends numpy
+// down its (i / div) * delta + start formula for every column
+Vec6 linspace_rows(const Vec6 &lo, const Vec6 &hi, int num, int i)
+{
+    if (i == num - 1) return hi;
+    Vec6 r;
+    const double div = (double)(num - 1);
+    bool any_zero = false;
+    for (int j = 0; j < 6; j++) any_zero = any_zero || ((hi[j] - lo[j]) / div == 0.0);
+    for (int j = 0; j < 6; j++) {
+        const double delta = hi[j] - lo[j];
+        r[j] = any_zero ? ((double)i / div) * delta + lo[j] : (double)i * (delta / div) + lo[j];
+    }
+    return r;
+}
+
+// interp1d(x, y, kind='cubic')(xq): not-a-knot cubic spline through (x, y), x strictly increasing, n >= 4.
+// Unknowns are the second derivatives M at the knots; dense elimination with partial pivoting (n <= a few hundred).
+// A NaN among the y makes every output NaN, as interp1d's NaN path does.
+void cubic_not_a_knot(const std::vector<double> &x, const std::vector<double> &y, const std::vector<double> &xq, std::vector<double> &out)
+{
+    const int n = (int)x.size();
+    out.assign(xq.size(), std::numeric_limits<double>::quiet_NaN());
+    for (int i = 0; i < n; i++)
+        if (std::isnan(y[i])) return;
+    std::vector<double> h(n - 1);
+    for (int i = 0; i < n - 1; i++) {
+        h[i] = x[i + 1] - x[i];
+        if (!(h[i] > 0.0)) return;
+    }
+    std::vector<double> A((size_t)n * n, 0.0), M(n, 0.0);
+    auto at = [&](int r, int col) -> double & { return A[(size_t)r * n + col]; };
+    for (int i = 1; i < n - 1; i++) {
+        at(i, i - 1) = h[i - 1];
+        at(i, i) = 2.0 * (h[i - 1] + h[i]);
+        at(i, i + 1) = h[i];
+        M[i] = 6.0 * ((y[i + 1] - y[i]) / h[i] - (y[i] - y[i - 1]) / h[i - 1]);
+    }
+    at(0, 0) = h[1]; at(0, 1) = -(h[0] + h[1]); at(0, 2) = h[0];
+    at(n - 1, n - 3) = h[n - 2]; at(n - 1, n - 2) = -(h[n - 3] + h[n - 2]); at(n - 1, n - 1) = h[n - 3];
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        for (int r = k + 1; r < n; r++)
+            if (std::fabs(at(r, k)) > std::fabs(at(p, k))) p = r;
+        if (p != k) {
+            for (int col = 0; col < n; col++) std::swap(at(k, col), at(p, col));
+            std::swap(M[k], M[p]);
+        }
+        for (int r = k + 1; r < n; r++) {
+            const double f = at(r, k) / at(k, k);
+            if (f == 0.0) continue;
+            for (int col = k; col < n; col++) at(r, col) -= f * at(k, col);
+            M[r] -= f * M[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double s = M[k];
+        for (int col = k + 1; col < n; col++) s -= at(k, col) * M[col];
+        M[k] = s / at(k, k);
+    }
+    for (size_t q = 0; q < xq.size(); q++) {
+        int i = 0;
+        while (i < n - 2 && xq[q] >= x[i + 1]) i++;
+        const double t0 = xq[q] - x[i], t1 = x[i + 1] - xq[q];
+        out[q] = (M[i] * t1 * t1 * t1 + M[i + 1] * t0 * t0 * t0) / (6.0 * h[i]) + (y[i] / h[i] - M[i] * h[i] / 6.0) * t1 +
+                 (y[i + 1] / h[i] - M[i + 1] * h[i] / 6.0) * t0;
+    }
+}
+
+// ---- Lookup (predict.py:165-171): argmin of the grid's lookup score
+int stage_lookup(Machine &m, const rope_stage &s, State &st)
+{
+    int32_t best = 0;
+    int rc;
+    if (m.a.use_table) rc = rope_lookup_score(m.c, nullptr, &best, nullptr);
+    else rc = rope_eval(m.c, m.a.lookup_angles, m.a.n_lookup, s.to_render, ROPE_LOSS_LOOKUP, m.a.lookup_crop, nullptr, nullptr, &best, nullptr);
+    if (rc) return rc;
+    m.evals += m.a.n_lookup;
+    if (best < 0 || best >= m.a.n_lookup) {
+        rope_set_error(m.c, "rope_predict: lookup argmin outside the grid (table built for another grid?)");
+        return ROPE_E_ARG;
+    }
+    for (int j = 0; j < 6; j++) st.angles[j] = m.a.lookup_angles[(size_t)best * 6 + j];
+    return ROPE_OK;
+}
+
+// ---- Descent (predict.py:173-230)
+int stage_descent(Machine &m, const rope_stage &s, State &st)
+{
+    for (int i = 0; i < 6; i++)
+        if (!std::isnan(s.init_rate[i])) st.lr[i] = s.init_rate[i];                 // predict.py:175-177
+    const int spec = m.a.speculate < 1 ? 1 : (m.a.speculate > 3 ? 3 : m.a.speculate);
+    std::vector<int> joints;
+    for (int j = 0; j < 6; j++)
+        if ((s.joints >> j) & 1u) joints.push_back(j);
+    double over_err = INF, under_err = INF;
+    std::vector<Vec6> rows, frontier, next;
+    for (int it = 0; it < s.count; it++) {
+        // step sizes of the whole iteration first: a joint's step depends on its own angle and on the history only,
+        // and neither changes before that joint's turn (predict.py:184-187)
+        for (int idx : joints) {
+            const double mean = ((((st.history[0][idx] + st.history[1][idx]) + st.history[2][idx]) + st.history[3][idx]) + st.history[4][idx]) / 5.0;
+            if (std::fabs(mean - st.angles[idx]) <= st.lr[idx]) st.lr[idx] *= s.rate_reduction;
+            for (int k = 0; k < 6; k++)
+                if (!(st.lr[k] >= m.a.min_ang_inc[k])) st.lr[k] = std::isnan(st.lr[k]) ? st.lr[k] : m.a.min_ang_inc[k];
+        }
+        // under/over of up to `spec` joints as one batch: the pair of every state the earlier decisions of the group
+        // can lead to (+step, -step, stay: 2, 6, 18 rows); the decisions are then read off in the reference's order
+        for (size_t g = 0; g < joints.size(); g += (size_t)spec) {
+            const int glen = (int)std::min(joints.size() - g, (size_t)spec);
+            int index[3][9][2];
+            for (auto &lv : index) for (auto &kk : lv) kk[0] = kk[1] = -1;
+            rows.clear();
+            frontier.assign(1, st.angles);
+            for (int level = 0; level < glen; level++) {
+                const int idx = joints[g + level];
+                next.clear();
+                for (size_t k = 0; k < frontier.size(); k++) {
+                    const Vec6 &state = frontier[k];
+                    Vec6 under = state;
+                    under[idx] -= st.lr[idx];
+                    Vec6 over = under;
+                    over[idx] += 2 * st.lr[idx];
+                    if (m.lim(idx, 0) <= under[idx] && under[idx] <= m.lim(idx, 1)) { index[level][k][0] = (int)rows.size(); rows.push_back(under); }
+                    if (m.lim(idx, 0) <= over[idx] && over[idx] <= m.lim(idx, 1)) { index[level][k][1] = (int)rows.size(); rows.push_back(over); }
+                    if (level + 1 < glen) {
+                        Vec6 up = state, down = state;
+                        up[idx] += st.lr[idx];
+                        down[idx] -= st.lr[idx];
+                        next.push_back(up); next.push_back(down); next.push_back(state);
+                    }
+                }
+                frontier.swap(next);
+            }
+            const int rc = m.errors(s.to_render, rows);
+            if (rc) return rc;
+            int k = 0;
+            for (int level = 0; level < glen; level++) {
+                const int idx = joints[g + level];
+                under_err = index[level][k][0] >= 0 ? m.err[index[level][k][0]] : INF;
+                over_err = index[level][k][1] >= 0 ? m.err[index[level][k][1]] : INF;
+                if (over_err < under_err) { st.angles[idx] += st.lr[idx]; k = 3 * k; }          // ties and NaN: stay (predict.py:212-215)
+                else if (over_err > under_err) { st.angles[idx] -= st.lr[idx]; k = 3 * k + 1; }
+                else k = 3 * k + 2;
+            }
+        }
+        push_front(st.history, st.angles);
+        push_front(st.err_history, HISTORY, under_err < over_err ? under_err : over_err);     // min(over, under) of the LAST joint (predict.py:222)
+        const double *eh = st.err_history;
+        const double mean_err = ((((eh[0] + eh[1]) + eh[2]) + eh[3]) + eh[4]) / 5.0;
+        if (std::fabs(mean_err - eh[0]) / eh[0] < s.early_stop) break;
+        bool settled = true, stuck = true;
+        for (int j = 0; j < 6; j++) {
+            double hi = st.history[0][j], lo = st.history[0][j];
+            for (int i = 1; i < HISTORY; i++) { hi = std::fmax(hi, st.history[i][j]); lo = std::fmin(lo, st.history[i][j]); }
+            const double spread = hi - lo, inc = m.a.min_ang_inc[j];
+            const bool close = std::fabs(spread - inc) <= 1e-8 + 1e-5 * std::fabs(inc);      // np.isclose defaults
+            settled = settled && (spread <= inc || close);
+            for (int i = 1; i < 3; i++) stuck = stuck && st.history[i][j] == st.history[0][j];
+        }
+        if (settled || stuck) break;
+    }
+    return ROPE_OK;
+}
+
+// ---- SFlip (predict.py:232-281)
+int stage_sflip(Machine &m, const rope_stage &s, State &st)
+{
+    const double *cam = m.a.camera_pose;
+    Vec6 temp = st.angles;
+    const double axis = cam[5] * std::fabs(std::cos(cam[3])) + cam[4] * std::fabs(std::sin(cam[3]));     // predict.py:245
+    const double sign = temp[0] > 0.0 ? 1.0 : (temp[0] < 0.0 ? -1.0 : temp[0]);                       // np.sign
+    temp[0] = -temp[0] + 2 * axis * sign;
+    const bool close_to_limits = 0.15 > std::fabs(m.lim(0, 0) - temp[0]) || 0.15 > std::fabs(m.lim(0, 1) - temp[0]);
+    const bool in_limits = m.lim(0, 0) <= temp[0] && temp[0] <= m.lim(0, 1);
+    // every pose this stage can ask for is known before the first answer: one batch of up to three rows
+    std::vector<Vec6> rows{st.angles};
+    if (in_limits) rows.push_back(temp);
+    if (!in_limits || close_to_limits) {
+        Vec6 endpoint = temp;
+        endpoint[0] = m.lim(0, 1);
+        rows.push_back(endpoint);
+    }
+    const int rc = m.errors(s.to_render, rows);
+    if (rc) return rc;
+    double base_err = m.err[0];
+    bool aliased = false;                           // `angles = temp` binds both names to one array (predict.py:261)
+    if (in_limits && m.err[1] < base_err) { st.angles = temp; aliased = true; base_err = m.err[1]; }
+    if (!in_limits || close_to_limits) {
+        // predict.py:270-277: both endpoints are written into temp, the comparison sits after the loop, so only the
+        // upper limit's error is used — and an accepted flip IS temp, so its S angle becomes the upper limit regardless
+        temp[0] = m.lim(0, 1);
+        if (aliased) st.angles = temp;
+        if (m.err.back() < base_err) st.angles = temp;
+    }
+    return ROPE_OK;
+}
+
+// ---- InterpolativeSweep (predict.py:283-338)
+int stage_isweep(Machine &m, const rope_stage &s, State &st)
+{
+    const int div = s.count;
+    bool have_base = false;                         // base_err is not refreshed between joints (predict.py:288-289)
+    double base_err = 0.0;
+    std::vector<Vec6> rows, space(div);
+    std::vector<double> xs(div), space_err(div), xq((size_t)div * 5), pred;
+    for (int idx = 0; idx < 6; idx++) {
+        if (!((s.joints >> idx) & 1u)) continue;
+        Vec6 lo = st.angles, hi = st.angles;
+        if (std::isnan(s.range)) { lo[idx] = m.lim(idx, 0); hi[idx] = m.lim(idx, 1); }
+        else {
+            const double l = lo[idx] - s.range, h = hi[idx] + s.range;
+            lo[idx] = m.lim(idx, 0) > l ? m.lim(idx, 0) : l;                    // max(a - range, lower limit)
+            hi[idx] = m.lim(idx, 1) < h ? m.lim(idx, 1) : h;                    // min(a + range, upper limit)
+        }
+        for (int i = 0; i < div; i++) space[i] = linspace_rows(lo, hi, div, i);
+        rows.clear();
+        if (!have_base) rows.push_back(st.angles);                              // the base pose rides along with the first sweep
+        rows.insert(rows.end(), space.begin(), space.end());
+        int rc = m.errors(s.to_render, rows);
+        if (rc) return rc;
+        const int off = have_base ? 0 : 1;
+        if (!have_base) { base_err = m.err[0]; have_base = true; }
+        for (int i = 0; i < div; i++) { space_err[i] = m.err[off + i]; xs[i] = space[i][idx]; }
+        for (int i = 0; i < div * 5; i++) xq[i] = linspace_scalar(lo[idx], hi[idx], div * 5, i);
+        cubic_not_a_knot(xs, space_err, xq, pred);
+        Vec6 angs = st.angles;
+        angs[idx] = xq[np_argmin(pred)];
+        rc = m.errors(s.to_render, std::vector<Vec6>{angs});
+        if (rc) return rc;
+        const double pred_min_err = m.err[0];
+        const int best_sample = py_argmin(space_err.data(), div);
+        const double errs[3] = {base_err, space_err[best_sample], pred_min_err};
+        const int min_type = py_argmin(errs, 3);                                // ties go to the earlier entry
+        if (min_type == 1) { st.angles = space[best_sample]; push_front(st.err_history, HISTORY, space_err[best_sample]); }
+        else if (min_type == 2) { st.angles = angs; push_front(st.err_history, HISTORY, pred_min_err); }
+        push_front(st.history, st.angles);
+    }
+    return ROPE_OK;
+}
+
+}  // namespace
+
+extern "C" int rope_predict(rope_ctx *c, const rope_predict_args *a, double *angles_out, double *trace_out, int64_t *n_evals)
+{
+    if (!c) return ROPE_E_ARG;
+    auto fail = [&](const char *msg) { rope_set_error(c, msg); return (int)ROPE_E_ARG; };
+    if (!a || !angles_out) return fail("rope_predict: null pointer");
+    if (!a->stages || a->n_stages < 1) return fail("rope_predict: no stages");
+    if (!a->limits || !a->camera_pose || !a->min_ang_inc) return fail("rope_predict: limits, camera_pose and min_ang_inc are required");
+    for (int i = 0; i < a->n_stages; i++) {
+        const rope_stage &s = a->stages[i];
+        switch (s.kind) {
+        case ROPE_STAGE_LOOKUP:
+            if (!a->lookup_angles || a->n_lookup < 1) return fail("rope_predict: a Lookup stage needs the pose grid");
+            if (!a->use_table && !a->lookup_crop) return fail("rope_predict: a Lookup stage without a stored table needs the crop");
+            break;
+        case ROPE_STAGE_DESCENT:
+            if (s.count < 0) return fail("rope_predict: Descent iterations must be >= 0");
+            break;
+        case ROPE_STAGE_SFLIP:
+            break;
+        case ROPE_STAGE_ISWEEP:
+            if (s.count < 4) return fail("rope_predict: InterpolativeSweep needs at least 4 divisions (cubic interpolation)");
+            break;
+        default:
+            return fail("rope_predict: unknown stage kind");
+        }
+        if (s.to_render < 1 || s.to_render > ROPE_MAX_LINKS) return fail("rope_predict: to_render must be 1..6");
+    }
+    Machine m{c, *a};
+    State st;
+    for (int i = 0; i < a->n_stages; i++) {
+        const rope_stage &s = a->stages[i];
+        int rc = ROPE_OK;
+        switch (s.kind) {
+        case ROPE_STAGE_LOOKUP: rc = stage_lookup(m, s, st); break;
+        case ROPE_STAGE_DESCENT: rc = stage_descent(m, s, st); break;
+        case ROPE_STAGE_SFLIP: rc = stage_sflip(m, s, st); break;
+        case ROPE_STAGE_ISWEEP: rc = stage_isweep(m, s, st); break;
+        }
+        if (rc) return rc;
+        if (trace_out)
+            for (int j = 0; j < 6; j++) trace_out[(size_t)i * 6 + j] = st.angles[j];
+    }
+    for (int j = 0; j < 6; j++) angles_out[j] = st.angles[j];
+    if (n_evals) *n_evals = m.evals;
+    return ROPE_OK;
+}

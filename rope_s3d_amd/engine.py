@@ -21,7 +21,23 @@ ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip',
-    'rope_set_frames', 'rope_eval_views')
+    'rope_set_frames', 'rope_eval_views', 'rope_predict')
+
+
+STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP = 0, 1, 2, 3
+
+
+class StageDesc(C.Structure):
+    """rope_stage (include/rope_s3d.h)."""
+    _fields_ = [('kind', C.c_int32), ('to_render', C.c_int32), ('count', C.c_int32), ('joints', C.c_uint32),
+                ('init_rate', C.c_double * 6), ('rate_reduction', C.c_double), ('early_stop', C.c_double), ('range', C.c_double)]
+
+
+class PredictArgs(C.Structure):
+    """rope_predict_args (include/rope_s3d.h)."""
+    _fields_ = [('stages', C.POINTER(StageDesc)), ('n_stages', C.c_int32), ('speculate', C.c_int32),
+                ('limits', C.c_void_p), ('camera_pose', C.c_void_p), ('min_ang_inc', C.c_void_p),
+                ('lookup_angles', C.c_void_p), ('n_lookup', C.c_int32), ('use_table', C.c_int32), ('lookup_crop', C.c_void_p)]
 
 
 class EngineUnavailable(RuntimeError):
@@ -69,6 +85,7 @@ def load_library(path: str = None):
     lib.rope_debug_mvp.argtypes = [vp, vp, i32, i32]
     lib.rope_profile_eval.argtypes = [vp, i32, i32, vp, i32, vp]
     lib.rope_debug_skip.argtypes = [vp, i32]
+    lib.rope_predict.argtypes = [vp, C.POINTER(PredictArgs), vp, vp, C.POINTER(C.c_int64)]
     lib.rope_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
     _lib = lib
@@ -218,6 +235,22 @@ class Engine:
         bi, be = C.c_int32(), C.c_double()
         self._check(self._lib.rope_lookup_score(self._ctx, _p(scores), C.byref(bi), C.byref(be)), 'rope_lookup_score')
         return scores, int(bi.value), float(be.value)
+
+    def predict(self, stages, limits, camera_pose, min_ang_inc, lookup_angles=None, lookup_crop=None, use_table=False,
+                speculate: int = 3):
+        """rope_predict: the whole stage machine of one frame in one call.  `stages` = StageDesc array (or list).
+        -> (angles (6,), trace (n_stages, 6), candidate poses evaluated)."""
+        arr = stages if isinstance(stages, C.Array) else (StageDesc * len(stages))(*stages)
+        limits = np.ascontiguousarray(limits, np.float64).reshape(6, 2)
+        cam = np.ascontiguousarray(camera_pose, np.float64).reshape(6)
+        inc = np.ascontiguousarray(min_ang_inc, np.float64).reshape(6)
+        grid = np.ascontiguousarray(lookup_angles, np.float64).reshape(-1, 6) if lookup_angles is not None else None
+        crop = np.ascontiguousarray(lookup_crop, np.int32).reshape(4) if lookup_crop is not None else None
+        a = PredictArgs(arr, len(arr), int(speculate), _p(limits), _p(cam), _p(inc), _p(grid), 0 if grid is None else len(grid),
+                        1 if use_table else 0, _p(crop))
+        out, trace, n = np.empty(6), np.empty((len(arr), 6)), C.c_int64()
+        self._check(self._lib.rope_predict(self._ctx, C.byref(a), _p(out), _p(trace), C.byref(n)), 'rope_predict')
+        return out, trace, int(n.value)
 
     def render(self, q, n_render: int = 6):
         """-> (depth float32 HxW metres, link id uint8 HxW with 255 = background)."""

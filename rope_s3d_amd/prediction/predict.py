@@ -15,7 +15,8 @@ import numpy as np
 
 from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
 from ..crop import Crop
-from ..engine import LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, pack_target
+from ..engine import (LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, StageDesc,
+                      pack_target)
 from ..imgproc import dilate, erode, resize_linear
 from ..projection import Intrinsics
 from ..simulation.lookup import RobotLookupManager
@@ -75,6 +76,7 @@ def segment_targets(seg: dict, target_depth: np.ndarray, lookup_links) -> np.nda
 class Predictor:
 
     SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
+    NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
 
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
@@ -162,6 +164,31 @@ class Predictor:
         if self.stages is None:
             raise ValueError(f"Stages not defined for joint set {self.do_angles}. "
                              "Please define in rope_s3d_amd/prediction/stages.py.")
+
+    def _native_stages(self):
+        """self.stages as rope_stage descriptors (include/rope_s3d.h), or None when a stage has no native form."""
+        nan = float('nan')
+        out = (StageDesc * len(self.stages))()
+        for d, stage in zip(out, self.stages):
+            d.init_rate[:] = [nan] * 6
+            d.range = nan
+            if type(stage) is Lookup:
+                d.kind, d.to_render = STAGE_LOOKUP, LOOKUP_NUM_RENDERED
+                continue
+            if type(stage) is SFlip:
+                d.kind, d.to_render = STAGE_SFLIP, stage.to_render
+                continue
+            d.joints = sum(1 << j for j in range(6) if stage.joints[j])
+            if type(stage) is Descent:
+                d.kind, d.to_render, d.count = STAGE_DESCENT, stage.to_render, stage.its
+                d.init_rate[:] = [nan if r is None else float(r) for r in stage.init_rate]
+                d.rate_reduction, d.early_stop = stage.rate_redux, stage.early_stop
+            elif type(stage) is InterpolativeSweep and stage.divs >= 4:
+                d.kind, d.to_render, d.count = STAGE_ISWEEP, stage.to_render, stage.divs
+                d.range = nan if stage.range is None else float(stage.range)
+            else:
+                return None
+        return out
 
     # ------------------------------------------------------------------ target preparation
     def _downsample(self, base: np.ndarray, factor: int) -> np.ndarray:
@@ -288,6 +315,13 @@ class Predictor:
         angles = np.array([0] * 6, dtype=float)
         self._setStages()
         self.trace = []
+        native = self._native_stages() if (self.NATIVE and not self.preview) else None
+        if native is not None:
+            angles, trace, n = self.engine.predict(native, limits, self.camera_pose, self.min_ang_inc, self.lookup_angles,
+                                                   self.lookup_crop, self._lookup_table, self.SPECULATE)
+            self.evaluations += n
+            self.trace = [(type(stage).__name__, trace[i].copy()) for i, stage in enumerate(self.stages)]
+            return angles
 
         for stage in self.stages:
             if type(stage) is Lookup:

@@ -320,3 +320,44 @@ def test_preview_shows_the_reference_render_sequence(synth, tmp_path):
     size = os.path.getsize(video)
     per_frame = 8 + 1280 * 720 * 3
     assert (size - p.viz.shown * per_frame) < 4096 and size > p.viz.shown * per_frame
+
+
+@pytest.mark.parametrize('do_angles', ['SLU', 'SL'])
+def test_native_stage_machine_matches_python_loop(do_angles):
+    """rope_predict (the stage loop in librope_hip.so) against Predictor's Python loop on the same frames: same angles
+    after every stage, same number of poses evaluated — with the reference's serial descent order and with the
+    speculative batches."""
+    from rope_s3d_amd import SyntheticPredictor
+    sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '640_480_color', 4, do_angles, noise=False, seed=3, lookup_divisions=5)
+    p = sp.predictor
+    lim = helpers.robot().joint_limits
+    for seed in range(int(os.environ.get('ROPE_NATIVE_SEEDS', '6'))):
+        q = np.random.default_rng(1000 + seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+        sp.renderer.setJointAngles(q)
+        color, depth = sp.renderer.render()
+        runs = {}
+        for native, spec in ((True, 3), (False, 3), (True, 1), (False, 1)):
+            p.NATIVE, p.SPECULATE, p.evaluations = native, spec, 0
+            got = p.run(color, depth)
+            runs[(native, spec)] = (got, [t[1] for t in p.trace], [t[0] for t in p.trace], p.evaluations)
+        p.NATIVE, p.SPECULATE = True, 3
+        for spec in (3, 1):
+            a, b = runs[(True, spec)], runs[(False, spec)]
+            assert a[2] == b[2]
+            for k, (ta, tb) in enumerate(zip(a[1], b[1])):
+                assert np.array_equal(ta, tb), (seed, spec, k, a[2][k], ta, tb)
+            assert np.array_equal(a[0], b[0]) and a[3] == b[3]
+        assert np.array_equal(runs[(True, 3)][0], runs[(True, 1)][0])
+
+
+def test_native_stage_machine_argument_errors(synth):
+    from rope_s3d_amd.engine import STAGE_ISWEEP, STAGE_LOOKUP, EngineError, StageDesc
+    p = synth.predictor
+    lim = helpers.robot().joint_limits
+    bad = StageDesc(STAGE_ISWEEP, 6, 3, 4)                    # three divisions: no cubic through them
+    with pytest.raises(EngineError, match='at least 4 divisions'):
+        p.engine.predict([bad], lim, DEFAULT_CAMERA_POSE, p.min_ang_inc)
+    with pytest.raises(EngineError, match='needs the pose grid'):
+        p.engine.predict([StageDesc(STAGE_LOOKUP, 6)], lim, DEFAULT_CAMERA_POSE, p.min_ang_inc)
+    with pytest.raises(EngineError, match='unknown stage kind'):
+        p.engine.predict([StageDesc(9, 6)], lim, DEFAULT_CAMERA_POSE, p.min_ang_inc)

@@ -21,6 +21,8 @@ intr = sys.argv[3] if len(sys.argv) > 3 else '1280_720_color'
 div = int(sys.argv[4]) if len(sys.argv) > 4 else None
 sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, intr, ds, 'SLU', noise=False, seed=1, lookup_divisions=div)
 p = sp.predictor
+p.NATIVE = os.environ.get('ROPE_NATIVE', '1') != '0'       # 0: the Python stage loop instead of rope_predict
+print(f"stage loop: {'rope_predict (C++)' if p.NATIVE else 'Python'}")
 print(f"render {p.intrinsics.width}x{p.intrinsics.height}, lookup grid {len(p.lookup_angles)} poses, crop {list(p.lookup_crop)}")
 lim = sp.urdf_reader.joint_limits
 poses = [np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]) for f in range(n)]
