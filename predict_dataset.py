@@ -61,8 +61,9 @@ def run(args):
         seg = None if am.synthetic else getattr(am, 'seg', None)
         if hasattr(seg, 'announce'):                          # the chunk's frames through the network in batches of 8
             seg.announce([am._downsample(og_imgs[i], am.ds_factor) for i in range(end - start)])
-        for i in range(end - start):
-            out[start - lo + i] = am.run(og_imgs[i], dms[i], cam_poses[i])
+        # frame by frame as predict_dataset.py:43-44, with the next frame's host preparation (down-sampling, masks,
+        # segmentation) running beside the current frame's device work
+        out[start - lo:end - lo] = am.run_many(og_imgs, dms, cam_poses)
     full = gather_rows(out, ds.length, device=device)
     if rank == 0:
         np.save(f'predictions_{os.path.basename(os.path.normpath(args.dataset))}.npy', full)

@@ -9,6 +9,7 @@ reference (predict.py:159-161,475-509) becomes one row of a batch handed to the 
 engine, which does FK, rasterisation and the error reduction on the device.
 """
 import warnings
+from dataclasses import dataclass
 from typing import Callable, Optional
 
 import numpy as np
@@ -54,6 +55,17 @@ def _not_a_knot(x, y, xq):
     t0, t1 = xq - x[i], x[i + 1] - xq
     return (M[i] * t1 ** 3 + M[i + 1] * t0 ** 3) / (6 * h[i]) + (y[i] / h[i] - M[i] * h[i] / 6) * t1 \
         + (y[i + 1] / h[i] - M[i + 1] * h[i] / 6) * t0
+
+
+@dataclass
+class PreparedTarget:
+    """One frame as the engine takes it (Predictor.prepare): everything _load_target caches in the reference."""
+    tgt_depth: np.ndarray          # (H, W) float64, body-masked on the segmentation path
+    lookup_f32: np.ndarray         # (H, W) float32 depth under the lookup links
+    target_masks: dict             # link name -> bool mask
+    tq: np.ndarray                 # packed uint64 plane (engine.pack_target)
+    flags: np.ndarray              # (8,) uint8 per-link flags
+    links_image: Optional[np.ndarray] = None     # what the preview shows as "detected links"
 
 
 def segment_targets(seg: dict, target_depth: np.ndarray, lookup_links) -> np.ndarray:
@@ -208,27 +220,30 @@ class Predictor:
                 out[name]['confidence'] = max(out[name]['confidence'], data['scores'][idx])
         return out
 
-    def _upload_target(self, tgt_depth: np.ndarray, lookup_depth: np.ndarray, masks: dict):
-        """Hand the frame's target to the engine: what _load_target caches in the reference
-        (predict.py:397-413) becomes one packed plane + per-link flags in HBM."""
-        self._tgt_depth = tgt_depth
-        self._lookup_depth_f32 = np.ascontiguousarray(lookup_depth, dtype=np.float32)
-        self._target_masks = {}
+    def _pack_target(self, tgt_depth: np.ndarray, lookup_depth: np.ndarray, masks: dict, links_image=None) -> PreparedTarget:
+        """What _load_target caches in the reference (predict.py:397-413), as one packed plane + per-link flags.
+        Host work only: nothing of the Predictor or the engine changes here."""
+        lookup_f32 = np.ascontiguousarray(lookup_depth, dtype=np.float32)
+        target_masks = {}
         bits = np.zeros(tgt_depth.shape, np.uint8)
         flags = np.zeros(8, np.uint8)
         has_depth = tgt_depth != 0
         for l, link in enumerate(self.link_names):
             if link in masks:
                 m = np.asarray(masks[link], dtype=bool)
-                self._target_masks[link] = m
+                target_masks[link] = m
                 bits |= m.view(np.uint8) << np.uint8(l)
                 flags[l] |= 1
                 # predict.py:495: np.sum(mask * depth != 0) > .05 * np.sum(mask), a target-only fact (counted, not multiplied)
                 if np.count_nonzero(m & has_depth) > (.05 * np.count_nonzero(m)):
                     flags[l] |= 2
-        self._tq = pack_target(tgt_depth, bits)
-        self._flags = flags
-        self.engine.set_target(self._tq, self._lookup_depth_f32, flags)
+        return PreparedTarget(tgt_depth, lookup_f32, target_masks, pack_target(tgt_depth, bits), flags, links_image)
+
+    def _install(self, prep: PreparedTarget):
+        """The frame's target into HBM; from here on the stages score against it."""
+        self._tgt_depth, self._lookup_depth_f32, self._target_masks = prep.tgt_depth, prep.lookup_f32, prep.target_masks
+        self._tq, self._flags, self._preview_links = prep.tq, prep.flags, prep.links_image
+        self.engine.set_target(prep.tq, prep.lookup_f32, prep.flags)
 
     def _segmentLoad(self, target_color, target_depth):
         """Segmentation path (predict.py:415-442).  NB: like the reference, zeroes target_depth in place."""
@@ -239,16 +254,14 @@ class Predictor:
         small = self._downsample(target_color, self.ds_factor)
         r = self.seg(small)
         seg = self._reorganize_by_link(r)
-        if self.preview:                  # pixellib hands back the frame with its masks painted on (predict.py:416)
-            self._preview_links = self._paint_links(small, seg)
+        # pixellib hands back the frame with its masks painted on (predict.py:416): only the preview looks at it
+        links_image = self._paint_links(small, seg) if self.preview else None
         lookup_depth = segment_targets(seg, target_depth, self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED])
-        self._upload_target(target_depth, lookup_depth, {k: v['mask'] for k, v in seg.items()})
-        return target_depth
+        return self._pack_target(target_depth, lookup_depth, {k: v['mask'] for k, v in seg.items()}, links_image)
 
     def _loadSynthetic(self, target_color, target_depth):
         """Synthetic path: link masks are read off channel 0 of the colour render (predict.py:445-469)."""
         target_color = self._downsample(target_color, self.ds_factor)
-        self._preview_links = target_color                    # `output` of predict.py:469
         blue = target_color[..., 0]
         hit = np.zeros(target_depth.shape, bool)            # the reference sums the comparisons and casts to bool (predict.py:449-454)
         for k in self.color_dict:
@@ -260,8 +273,41 @@ class Predictor:
             m = blue == self.color_dict[link][0]
             if m.any():                                        # np.sum(mask) > 0 (predict.py:465)
                 masks[link] = m
-        self._upload_target(target_depth, lookup_depth, masks)
-        return target_depth
+        return self._pack_target(target_depth, lookup_depth, masks, target_color)       # target_color: `output` of predict.py:469
+
+    def prepare(self, target_color, target_depth) -> PreparedTarget:
+        """The host half of run(): down-sampling, link masks (colour read-off or the segmenter), body masking and
+        packing (predict.py:132-137).  Touches neither the engine nor the Predictor's state, so the next frame can
+        be prepared while this one is on the GPU (run_many)."""
+        target_depth = self._downsample(np.asarray(target_depth), self.ds_factor)
+        if target_depth.dtype != np.float64:
+            target_depth = target_depth.astype(np.float64)
+        if self.synthetic:
+            return self._loadSynthetic(target_color, target_depth)
+        return self._segmentLoad(target_color, target_depth)
+
+    def run_many(self, target_colors, target_depths, camera_poses=None, prefetch: bool = True) -> np.ndarray:
+        """run() over a sequence of frames -> (N, 6).  With prefetch, frame i+1 is prepared on a worker thread while
+        frame i's stages run on the GPU (numpy and the library both release the interpreter lock); the frames are
+        still predicted one after the other, in order, each from a fresh state — same angles as a loop of run()."""
+        n = len(target_colors)
+        out = np.zeros((n, 6))
+        if n == 0:
+            return out
+        pose = (lambda i: None) if camera_poses is None else (lambda i: camera_poses[i])
+        if not prefetch or self.preview or n == 1:
+            for i in range(n):
+                out[i] = self.run(target_colors[i], target_depths[i], pose(i))
+            return out
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(self.prepare, target_colors[0], target_depths[0])
+            for i in range(n):
+                prep = nxt.result()
+                if i + 1 < n:
+                    nxt = pool.submit(self.prepare, target_colors[i + 1], target_depths[i + 1])
+                out[i] = self.run(None, None, pose(i), prepared=prep)
+        return out
 
     # ------------------------------------------------------------------ evaluation
     def _errors(self, n_render: int, candidates: np.ndarray) -> list:
@@ -292,20 +338,14 @@ class Predictor:
         return np.rint(out).astype(np.uint8)
 
     # ------------------------------------------------------------------ the state machine
-    def run(self, target_color, target_depth, camera_pose=None):
+    def run(self, target_color, target_depth, camera_pose=None, *, prepared: PreparedTarget = None):
         if camera_pose is not None and np.any(np.asarray(camera_pose) != self.camera_pose):
             self.changeCameraPose(camera_pose)
 
-        target_depth = self._downsample(np.asarray(target_depth), self.ds_factor)
-        if target_depth.dtype != np.float64:
-            target_depth = target_depth.astype(np.float64)
-        if self.synthetic:
-            self._loadSynthetic(target_color, target_depth)
-        else:
-            self._segmentLoad(target_color, target_depth)
+        self._install(prepared if prepared is not None else self.prepare(target_color, target_depth))
         if self.preview:
             self.viz.loadTargetColor(target_color)
-            self.viz.loadTargetDepth(target_depth)
+            self.viz.loadTargetDepth(self._tgt_depth)
             self.viz.loadSegmentedLinks(self._preview_links)
 
         limits = self.u_reader.joint_limits

@@ -361,3 +361,26 @@ def test_native_stage_machine_argument_errors(synth):
         p.engine.predict([StageDesc(STAGE_LOOKUP, 6)], lim, DEFAULT_CAMERA_POSE, p.min_ang_inc)
     with pytest.raises(EngineError, match='unknown stage kind'):
         p.engine.predict([StageDesc(9, 6)], lim, DEFAULT_CAMERA_POSE, p.min_ang_inc)
+
+
+def test_run_many_prefetch_equals_frame_by_frame(synth):
+    """Predictor.run_many prepares frame i+1 on a worker thread while frame i is on the GPU: same angles as a loop of
+    run(), with and without the thread, on the colour path and on the segmenter path."""
+    from rope_s3d_amd import Predictor
+    from rope_s3d_amd.segmentation import ColorSegmenter
+    p = synth.predictor
+    lim = helpers.robot().joint_limits
+    colors, depths = [], []
+    for seed in range(5):
+        q = np.random.default_rng(50 + seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+        synth.renderer.setJointAngles(q)
+        c, d = synth.renderer.render()
+        colors.append(c); depths.append(d)
+    want = np.array([p.run(c, d) for c, d in zip(colors, depths)])
+    assert np.array_equal(p.run_many(colors, depths), want)
+    assert np.array_equal(p.run_many(colors, depths, [DEFAULT_CAMERA_POSE] * 5, prefetch=False), want)
+    assert p.run_many([], []).shape == (0, 6)
+    seg = Predictor(DEFAULT_CAMERA_POSE, 4, base_intrin='640_480_color', segmenter=ColorSegmenter(p.classes, split_instances=True),
+                    lookup_divisions=4)
+    want_seg = np.array([seg.run(c, d.astype(np.float64)) for c, d in zip(colors, depths)])
+    assert np.array_equal(seg.run_many(colors, [d.astype(np.float64) for d in depths]), want_seg)

@@ -36,8 +36,12 @@ for q in poses:
 p.evaluations = 0
 res = np.zeros((2, n, 6))
 t0 = time.perf_counter()
-for f in range(n):
-    res[0, f], res[1, f] = poses[f], p.run(*frames[f])
+if os.environ.get('ROPE_PREFETCH', '0') != '0':             # Predictor.run_many: frame i+1 prepared while frame i is on the GPU
+    res[0] = poses
+    res[1] = p.run_many([c for c, _ in frames], [d for _, d in frames])
+else:
+    for f in range(n):
+        res[0, f], res[1, f] = poses[f], p.run(*frames[f])
 dt = time.perf_counter() - t0
 st = joint_error_stats(res[1], res[0])
 print(f"{n} frames in {dt:.2f} s = {n / dt:.1f} frames/s, {p.evaluations / n:.0f} candidate evaluations/frame, "

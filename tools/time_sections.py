@@ -20,8 +20,12 @@ def wrap(obj, name):
     def g(*a, **k):
         t = time.perf_counter(); r = f(*a, **k); acc[name] = acc.get(name, 0) + time.perf_counter() - t; acc[name+'_n'] = acc.get(name+'_n', 0) + 1; return r
     setattr(obj, name, g)
-for n in ('_loadSynthetic', '_stage_lookup', '_stage_descent', '_stage_sflip', '_stage_isweep', '_errors', '_downsample', '_upload_target'):
+p.NATIVE = os.environ.get('ROPE_NATIVE', '1') != '0'
+for n in ('_loadSynthetic', '_stage_lookup', '_stage_descent', '_stage_sflip', '_stage_isweep', '_errors', '_downsample', '_upload_target', '_native_stages'):
     wrap(p, n)
+wrap(p.engine, 'predict')
+wrap(p.engine, 'lookup_score')
+wrap(p.engine, 'set_target')
 p.run(*frames[0])
 acc.clear()
 t0 = time.perf_counter()
