@@ -45,3 +45,4 @@ DEFAULT_RENDER_COLORS = render_colors(MAX_LINKS)
 LINK_BLUE = np.array([c[0] for c in DEFAULT_RENDER_COLORS], dtype=np.uint8)
 BACKGROUND_ID = 255
 VIDEO_FPS = 15      # default preview video frames per second (constants.py:58)
+JSON_LINK_FILE = r"\\marvin\ROPE\joint_states.json"      # where the controller drops its joint state (constants.py:16)

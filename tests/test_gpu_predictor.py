@@ -384,3 +384,38 @@ def test_run_many_prefetch_equals_frame_by_frame(synth):
                     lookup_divisions=4)
     want_seg = np.array([seg.run(c, d.astype(np.float64)) for c, d in zip(colors, depths)])
     assert np.array_equal(seg.run_many(colors, [d.astype(np.float64) for d in depths]), want_seg)
+
+
+def test_predict_live_replay_monitors_deviation(tmp_path, monkeypatch, capsys):
+    """predict_live.Live (predict_live.py:94-185) over a replayed dataset: predictions equal Predictor.run's, the
+    (2, n, 6) log is saved every frame, and a controller that lies about its pose flips the state after LENGTH frames."""
+    import importlib
+    from rope_s3d_amd.data.dataset import Dataset, make_synthetic_dataset
+    from rope_s3d_amd.prediction.feed import DatasetCamera
+    d = make_synthetic_dataset(str(tmp_path / 'live5'), 5, base_intrin='640_480_color', seed=7919)
+    ds = Dataset(d)
+    monkeypatch.chdir(tmp_path)
+    pl = importlib.import_module('predict_live')
+    cam = DatasetCamera(ds)
+    live = pl.Live(str(ds.intrinsics), ds, 'SLU', 4, camera=cam, link=cam.claims(), color_dict=ds.attrs['color_dict'], lookup_divisions=4)
+    assert live.run() == 5
+    live.stop()
+    log = np.load(tmp_path / 'live_preds.npy')
+    assert log.shape == (2, 5, 6) and np.array_equal(log[0], np.asarray(ds.angles))
+    want = np.array([live.pred.run(np.copy(ds.og_img[i]), np.copy(ds.depthmaps[i])) for i in range(5)])
+    assert np.array_equal(log[1], want)
+    assert not live.state and 'in range' in capsys.readouterr().out
+
+    class Lying:                                    # claims a pose a quarter turn of S away from the truth
+        def __init__(self, inner): self.inner = inner
+        def get_pose(self, timeout=None):
+            q = self.inner.get_pose()
+            return None if q is None else q + np.array([1.2, 0, 0, 0, 0, 0])
+        def reset(self, timeout=None): pass
+    cam = DatasetCamera(ds)
+    live = pl.Live(str(ds.intrinsics), ds, 'SLU', 4, camera=cam, link=Lying(cam.claims()), save_to=None,
+                   color_dict=ds.attrs['color_dict'], lookup_divisions=4)
+    states = []
+    while live.step():
+        states.append(live.state)
+    assert states == [False, False, True, True, True]

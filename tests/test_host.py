@@ -327,3 +327,29 @@ def test_projection_viz_frame_and_avi(tmp_path):
     assert raw[movi + 4:movi + 8] == b'00db' and len(raw) - (movi + 4) == 3 * (8 + 640 * 360 * 3)
     first = np.frombuffer(raw[movi + 12:movi + 12 + 640 * 360 * 3], np.uint8).reshape(360, 640, 3)[::-1]
     assert np.array_equal(first[180:, 320:], f[180:, 320:])
+
+
+def test_json_coupling_and_dataset_camera(tmp_path):
+    """The controller's JSON link (textfile_integration.py:19-69) and the replay camera of predict_live.py."""
+    import json
+    from rope_s3d_amd.prediction.feed import DatasetCamera, JSONCoupling, LiveCamera
+    link = JSONCoupling(str(tmp_path / 'joint_states.json'), poll=0.001)
+    assert link.get_pose(timeout=0.02) is None                       # nothing written yet
+    (tmp_path / 'joint_states.json').write_text('{"position": [0.1, 0.2, 0.3')        # controller mid-write
+    assert link.get_pose(timeout=0.02) is None
+    (tmp_path / 'joint_states.json').write_text(json.dumps({'position': [0.1, 0.2, 0.3, 0, 0, 0]}))
+    assert np.array_equal(link.get_pose(timeout=1), [0.1, 0.2, 0.3, 0, 0, 0])
+    link.reset(timeout=1)
+    assert not (tmp_path / 'joint_states.json').exists()
+    link.reset(timeout=0.01)                                          # nothing to remove: returns
+    with pytest.raises(RuntimeError, match='pyrealsense2'):
+        LiveCamera()
+    og = np.arange(2 * 4 * 6 * 3, dtype=np.uint8).reshape(2, 4, 6, 3)
+    d = write_dataset(str(tmp_path / 'two'), og, np.ones((2, 4, 6)), np.array([[1., 0, 0, 0, 0, 0], [2., 0, 0, 0, 0, 0]]),
+                      np.zeros((2, 6)), '[ 6x4  p[3 2]  f[5 5]  Brown Conrady [0 0 0 0 0] ]')
+    cam = DatasetCamera(Dataset(d))
+    claims = cam.claims()
+    assert claims.get_pose()[0] == 1.0
+    c, dm = cam.get()
+    assert np.array_equal(c, og[0]) and dm.shape == (4, 6) and claims.get_pose()[0] == 2.0
+    assert cam.get() is not None and cam.get() is None and claims.get_pose() is None
