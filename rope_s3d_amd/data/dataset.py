@@ -2,9 +2,11 @@
 robotpose/data/dataset.py:176-192): length, angles, positions, depthmaps, og_img, camera_pose,
 preview_img, intrinsics, attrs — sliceable, `np.copy(ds.x[a:b])` works (predict_dataset.py:39-41).
 
-Storage is a directory of .npy arrays (memory-mapped on load) + attrs.json instead of the
-reference's gzip HDF5 (h5py is not available in this image); the zip -> HDF5 builder is
-ingest tooling and out of scope.
+Two storage forms are read.  The reference's own: `<datasets>/<name>/<name>.h5`, gzip-chunked HDF5 with the groups
+of building.py:195-242 — through h5py when importable, else through the HDF5 C library (data/hdf5.py); frames are
+decompressed as they are sliced.  And a directory of .npy arrays (memory-mapped) + attrs.json, which needs neither
+and is what the synthetic-set generator writes.  The zip -> HDF5 builder is ingest tooling and out of scope
+(SURVEY §2 row 13); `write_h5_dataset` / `tools/convert_dataset.py` convert between the two forms.
 """
 import json
 import os
@@ -17,8 +19,34 @@ _ARRAYS = {'angles': 'angles.npy', 'positions': 'positions.npy', 'depthmaps': 'd
            'og_img': 'og_img.npy', 'camera_pose': 'camera_pose.npy', 'preview_img': 'preview_img.npy'}
 
 
+# dataset attribute -> path inside the HDF5 file (dataset.py:176-192)
+_H5_PATHS = {'angles': 'angles', 'positions': 'positions', 'depthmaps': 'coordinates/depthmaps', 'og_img': 'images/original',
+             'camera_pose': 'images/camera_poses', 'preview_img': 'images/preview'}
+
+
 def dataset_dir(name: str) -> str:
+    if name.endswith('.h5') and os.path.isfile(name):
+        return os.path.dirname(os.path.abspath(name))
     return name if os.path.isabs(name) or os.path.isdir(name) else os.path.join(Paths().DATASETS, name)
+
+
+def _h5_path(name: str, directory: str):
+    if name.endswith('.h5') and os.path.isfile(name):
+        return os.path.abspath(name)
+    cand = os.path.join(directory, os.path.basename(os.path.normpath(directory)) + '.h5')
+    return cand if os.path.isfile(cand) else None
+
+
+def _open_h5(path: str, mode: str):
+    """-> (file object with [] and .attrs, closer).  h5py first: it is what wrote the file."""
+    try:
+        import h5py
+        f = h5py.File(path, mode)
+        return f, dict(f.attrs)
+    except ImportError:
+        from .hdf5 import H5File
+        f = H5File(path, 'r' if mode == 'r' else 'r+')
+        return f, f.attrs
 
 
 class Dataset:
@@ -28,20 +56,35 @@ class Dataset:
             raise NotImplementedError("rebuilding from the raw zip is ingest tooling (out of scope)")
         self.name, self.permissions = name, permissions
         self.dataset_dir = dataset_dir(name)
-        if not os.path.isfile(os.path.join(self.dataset_dir, 'attrs.json')):
-            raise ValueError(f"The requested dataset is not available: {self.dataset_dir}")
+        self.file = None
+        self.dataset_path = _h5_path(name, self.dataset_dir)
+        if self.dataset_path is None and not os.path.isfile(os.path.join(self.dataset_dir, 'attrs.json')):
+            raise ValueError(f"The requested dataset is not available: {self.dataset_dir} holds neither "
+                             f"{os.path.basename(os.path.normpath(self.dataset_dir))}.h5 nor attrs.json")
         self.load()
 
     def load(self):
-        with open(os.path.join(self.dataset_dir, 'attrs.json')) as f:
-            self.attrs = json.load(f)
         mode = 'r' if self.permissions == 'r' else 'r+'
-        for attr, fn in _ARRAYS.items():
-            path = os.path.join(self.dataset_dir, fn)
-            setattr(self, attr, np.load(path, mmap_mode=mode) if os.path.exists(path) else None)
+        if os.path.isfile(os.path.join(self.dataset_dir, 'attrs.json')) and not (self.name.endswith('.h5') and self.dataset_path):
+            with open(os.path.join(self.dataset_dir, 'attrs.json')) as f:
+                self.attrs = json.load(f)
+            for attr, fn in _ARRAYS.items():
+                path = os.path.join(self.dataset_dir, fn)
+                setattr(self, attr, np.load(path, mmap_mode=mode) if os.path.exists(path) else None)
+        else:
+            self.file, self.attrs = _open_h5(self.dataset_path, mode)
+            for attr, path in _H5_PATHS.items():
+                setattr(self, attr, self.file[path] if path in self.file else None)
+            if isinstance(self.attrs.get('color_dict'), str):          # a dict has no HDF5 form: stored as JSON text
+                self.attrs['color_dict'] = json.loads(self.attrs['color_dict'])
         self.length = int(self.attrs['length'])
         self.og_resolution = self.attrs.get('resolution')
-        self.intrinsics = self.attrs['color_intrinsics']
+        self.intrinsics = str(self.attrs['color_intrinsics'])
+
+    def close(self):
+        if self.file is not None:
+            self.file.close()
+            self.file = None
 
     def __len__(self) -> int:
         return self.length
@@ -88,3 +131,18 @@ def make_synthetic_dataset(name: str, n_frames: int, base_intrin: str = '640_480
         ang[f] = q
     return write_dataset(name, og, dm, ang, np.tile(pose, (n_frames, 1)), str(r.intrinsics),
                          extra_attrs={'synthetic': True, 'color_dict': r.color_dict})
+
+
+def write_h5_dataset(name: str, og_img, depthmaps, angles, camera_pose, color_intrinsics: str, positions=None,
+                     extra_attrs: dict = None, compression_level: int = 4) -> str:
+    """The same arrays as one `<name>/<name>.h5` in the reference's layout (building.py:195-242): what the reference's
+    own Dataset class opens.  Needs the HDF5 C library (data/hdf5.py)."""
+    from . import hdf5
+    d = dataset_dir(name)
+    os.makedirs(d, exist_ok=True)
+    attrs = {}
+    for k, v in (extra_attrs or {}).items():
+        attrs[k] = json.dumps(v) if isinstance(v, dict) else (int(v) if isinstance(v, bool) else v)
+    path = os.path.join(d, os.path.basename(os.path.normpath(d)) + '.h5')
+    return hdf5.write_h5_dataset(path, og_img, depthmaps, angles, camera_pose, color_intrinsics, positions, attrs=attrs,
+                                 compression_level=compression_level)

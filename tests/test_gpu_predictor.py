@@ -419,3 +419,24 @@ def test_predict_live_replay_monitors_deviation(tmp_path, monkeypatch, capsys):
     while live.step():
         states.append(live.state)
     assert states == [False, False, True, True, True]
+
+
+def test_predict_dataset_reads_the_reference_hdf5_form(tmp_path, monkeypatch):
+    """The same frames as .npy directory and as the reference's <name>/<name>.h5 (gzip-chunked): same predictions."""
+    import argparse
+    import importlib
+    from rope_s3d_amd.data import hdf5
+    from rope_s3d_amd.data.dataset import Dataset, make_synthetic_dataset, write_h5_dataset
+    if not hdf5.available():
+        pytest.skip("no libhdf5 on this machine")
+    d = make_synthetic_dataset(str(tmp_path / 'synth3'), 3, base_intrin='640_480_color', seed=7919)
+    a = Dataset(d)
+    h5 = write_h5_dataset(str(tmp_path / 'synth3h'), np.asarray(a.og_img), np.asarray(a.depthmaps), np.asarray(a.angles),
+                          np.asarray(a.camera_pose), a.intrinsics, extra_attrs={'synthetic': True, 'color_dict': a.attrs['color_dict']})
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    pd = importlib.import_module('predict_dataset')
+    want = pd.run(argparse.Namespace(dataset=d, angs='SLU', ds_factor=4))
+    got = pd.run(argparse.Namespace(dataset=os.path.dirname(h5), angs='SLU', ds_factor=4))
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.load(tmp_path / 'predictions_synth3h.npy'), want)

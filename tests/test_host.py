@@ -353,3 +353,41 @@ def test_json_coupling_and_dataset_camera(tmp_path):
     c, dm = cam.get()
     assert np.array_equal(c, og[0]) and dm.shape == (4, 6) and claims.get_pose()[0] == 2.0
     assert cam.get() is not None and cam.get() is None and claims.get_pose() is None
+
+
+def test_reference_hdf5_dataset_round_trip(tmp_path):
+    """The reference's storage form (building.py:195-242, dataset.py:176-192): a gzip-chunked <name>/<name>.h5 read
+    lazily through the HDF5 C library, frames sliced as predict_dataset.py:39-41 slices them."""
+    from rope_s3d_amd.data import hdf5
+    from rope_s3d_amd.data.dataset import write_h5_dataset
+    if not hdf5.available():
+        pytest.skip("no libhdf5 on this machine")
+    rng = np.random.default_rng(5)
+    n, H, W = 7, 36, 48
+    og = rng.integers(0, 255, (n, H, W, 3), dtype=np.uint8)
+    dm = rng.uniform(0, 3, (n, H, W)) * (rng.uniform(size=(n, H, W)) > .5)
+    ang, cam = rng.uniform(-1, 1, (n, 6)), np.tile(constants.DEFAULT_CAMERA_POSE, (n, 1)).astype(float)
+    intr = '[ 48x36  p[24 18]  f[40 40]  Brown Conrady [0 0 0 0 0] ]'
+    path = write_h5_dataset(str(tmp_path / 'set7'), og, dm, ang, cam, intr,
+                            extra_attrs={'synthetic': True, 'color_dict': {'base_link': [0, 0, 255]}, 'depth_scale': 0.001})
+    assert path == str(tmp_path / 'set7' / 'set7.h5') and os.path.getsize(path) < og.nbytes + dm.nbytes        # deflated
+    for name in (str(tmp_path / 'set7'), path):                   # by directory (the reference's way) and by file
+        ds = Dataset(name)
+        assert ds.length == n == len(ds.og_img) and ds.intrinsics == intr and list(ds.og_resolution) == [H, W]
+        assert ds.attrs['name'] == 'set7' and ds.attrs['synthetic'] == 1 and ds.attrs['color_dict'] == {'base_link': [0, 0, 255]}
+        assert ds.attrs['depth_scale'] == 0.001
+        assert ds.og_img.shape == (n, H, W, 3) and ds.og_img.dtype == np.uint8 and ds.depthmaps.dtype == np.float64
+        assert np.array_equal(np.copy(ds.og_img[2:5]), og[2:5]) and np.array_equal(np.copy(ds.depthmaps[2:5]), dm[2:5])
+        assert np.array_equal(ds.og_img[-1], og[-1]) and np.array_equal(ds.depthmaps[3, 10:20], dm[3, 10:20])
+        assert np.array_equal(np.copy(ds.angles), ang) and np.array_equal(ds.camera_pose[0], cam[0])
+        assert np.array_equal(ds.og_img[::3], og[::3]) and ds.og_img[4:4].shape == (0, H, W, 3)
+        assert ds.positions.shape == (n, 6, 3) and ds.preview_img.shape[0] == n
+        with pytest.raises(IndexError):
+            ds.og_img[n]
+        ds.close()
+    with pytest.raises(ValueError, match='not available'):
+        Dataset(str(tmp_path / 'nothing_here'))
+    (tmp_path / 'bad').mkdir()
+    (tmp_path / 'bad' / 'bad.h5').write_bytes(b'not an hdf5 file')
+    with pytest.raises(IOError):
+        Dataset(str(tmp_path / 'bad'))
