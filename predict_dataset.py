@@ -41,7 +41,10 @@ def run(args):
         # timing are meaningful.
         import torch
         from rope_s3d_amd.maskrcnn import MaskRCNNSegmenter
-        sd = torch.load(args.weights, map_location='cpu') if getattr(args, 'weights', None) else None
+        sd = None
+        if getattr(args, 'weights', None):                    # a trained Keras file of the reference (models/<set>/*.h5), or a state_dict
+            from rope_s3d_amd.maskrcnn import load_matterport_weights
+            sd = load_matterport_weights(args.weights) if args.weights.endswith('.h5') else torch.load(args.weights, map_location='cpu')
         from rope_s3d_amd.maskrcnn import BatchAheadSegmenter
         kwargs['segmenter'] = BatchAheadSegmenter(MaskRCNNSegmenter(7, device=f'cuda:{gpu}', state_dict=sd,
                                                                     min_confidence=0.7 if sd is not None else 0.0), batch=8)
@@ -82,5 +85,5 @@ if __name__ == "__main__":
     parser.add_argument('-ds_factor', type=int, default=8, help="Downsampling factor (the reference hard-codes 8).")
     parser.add_argument('-segmenter', type=str, default=None, choices=[None, 'maskrcnn'],
                         help="'maskrcnn': segment every frame with the Mask R-CNN stage instead of reading a synthetic set's colours.")
-    parser.add_argument('-weights', type=str, default=None, help="state_dict file for -segmenter maskrcnn (random weights otherwise).")
+    parser.add_argument('-weights', type=str, default=None, help="weights for -segmenter maskrcnn: the reference's trained Keras .h5 or a torch state_dict (random weights otherwise).")
     run(parser.parse_args())

@@ -74,6 +74,7 @@ def _declare(h):
         'H5Fopen': (_HID, [C.c_char_p, C.c_uint, _HID]), 'H5Fcreate': (_HID, [C.c_char_p, C.c_uint, _HID, _HID]),
         'H5Fclose': (C.c_int, [_HID]),
         'H5Gcreate2': (_HID, [_HID, C.c_char_p, _HID, _HID, _HID]), 'H5Gclose': (C.c_int, [_HID]),
+        'H5Gopen2': (_HID, [_HID, C.c_char_p, _HID]),
         'H5Lexists': (C.c_int, [_HID, C.c_char_p, _HID]),
         'H5Dopen2': (_HID, [_HID, C.c_char_p, _HID]), 'H5Dclose': (C.c_int, [_HID]),
         'H5Dcreate2': (_HID, [_HID, C.c_char_p, _HID, _HID, _HID, _HID, _HID]),
@@ -95,12 +96,16 @@ def _declare(h):
         'H5Aiterate2': (C.c_int, [_HID, C.c_int, C.c_int, C.POINTER(_HSZ), C.c_void_p, C.c_void_p]),
         'H5Pcreate': (_HID, [_HID]), 'H5Pset_chunk': (C.c_int, [_HID, C.c_int, C.POINTER(_HSZ)]),
         'H5Pset_deflate': (C.c_int, [_HID, C.c_uint]), 'H5Pclose': (C.c_int, [_HID]),
+        'H5Pset_create_intermediate_group': (C.c_int, [_HID, C.c_uint]),
         'H5Eset_auto2': (C.c_int, [_HID, C.c_void_p, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(h, name)
         f.restype, f.argtypes = res, args
     h.H5Eset_auto2(0, None, None)             # no error stack on stderr: failures become Python exceptions here
+    it = getattr(h, 'H5Literate', None) or getattr(h, 'H5Literate1')       # 1.12+ keeps the 1.10 form under this name
+    it.restype, it.argtypes = C.c_int, [_HID, C.c_int, C.c_int, C.POINTER(_HSZ), C.c_void_p, C.c_void_p]
+    h._iterate_links = it
 
 
 def _glob(name: str) -> int:
@@ -286,6 +291,29 @@ class H5File:
         self._open.append(a)
         return a
 
+    def walk(self, group: str = '/'):
+        """Paths of every dataset below `group`, depth first in name order."""
+        h, names = lib(), []
+
+        def visit(loc, name, info, data):
+            names.append(name.decode())
+            return 0
+        gid = h.H5Gopen2(self._id, group.encode(), 0)
+        if gid < 0:
+            raise KeyError(f"no group '{group}' in {self.filename}")
+        cb = _ATTR_CB(visit)
+        h._iterate_links(gid, 0, 0, None, C.cast(cb, C.c_void_p), None)
+        h.H5Gclose(gid)
+        base = group.rstrip('/')
+        for n in names:
+            path = f'{base}/{n}'
+            did = h.H5Dopen2(self._id, path.encode(), 0)
+            if did >= 0:
+                h.H5Dclose(did)
+                yield path.lstrip('/')
+            else:
+                yield from self.walk(path)
+
     @property
     def attrs(self) -> dict:
         """File (root group) attributes as Python values: str, int, float or numpy arrays."""
@@ -382,7 +410,10 @@ def _write_array(fid: int, path: str, data: np.ndarray, gzip: int = None):
         chunk = (_HSZ * rank)(1, *data.shape[1:])            # one frame per chunk: a slice of frames inflates only those
         h.H5Pset_chunk(dcpl, rank, chunk)
         h.H5Pset_deflate(dcpl, int(gzip))
-    did = h.H5Dcreate2(fid, path.encode(), _native(data.dtype), sid, 0, dcpl, 0)
+    lcpl = h.H5Pcreate(_glob('H5P_CLS_LINK_CREATE_ID_g'))          # groups on the way are made as needed
+    h.H5Pset_create_intermediate_group(lcpl, 1)
+    did = h.H5Dcreate2(fid, path.encode(), _native(data.dtype), sid, lcpl, dcpl, 0)
+    h.H5Pclose(lcpl)
     rc = h.H5Dwrite(did, _native(data.dtype), 0, 0, 0, data.ctypes.data_as(C.c_void_p)) if (did >= 0 and data.size) else (0 if did >= 0 else -1)
     if dcpl:
         h.H5Pclose(dcpl)
@@ -418,6 +449,24 @@ def write_h5_dataset(path: str, og_img, depthmaps, angles, camera_pose, color_in
         _write_array(fid, 'images/original', og_img, compression_level)
         _write_array(fid, 'images/preview', og_img[:, ::10, ::10] if preview is None else np.asarray(preview, np.uint8))
         _write_array(fid, 'images/camera_poses', np.asarray(camera_pose, np.float64))
+    finally:
+        h.H5Fclose(fid)
+    return path
+
+
+def write_arrays(path: str, arrays: dict, attrs: dict = None, gzip: int = None) -> str:
+    """A plain HDF5 file of named arrays ({'group/sub/name': ndarray}); groups are created as needed."""
+    h = lib()
+    if os.path.exists(path):
+        os.remove(path)
+    fid = h.H5Fcreate(path.encode(), H5F_ACC_TRUNC, 0, 0)
+    if fid < 0:
+        raise IOError(f"cannot create {path}")
+    try:
+        for k, v in (attrs or {}).items():
+            _write_attr(fid, k, v)
+        for name, data in arrays.items():
+            _write_array(fid, name, np.asarray(data), gzip)
     finally:
         h.H5Fclose(fid)
     return path

@@ -9,10 +9,11 @@ ResNet-101 C1..C5, FPN P2..P6, RPN over 5 scales x 3 ratios, proposal layer (top
 un-moulding of masks into the image.  PixelLib's inference config for this call: 512x512 square input,
 detection threshold 0.7 (pixellib custom_segmentation.inferConfig defaults).
 
-No trained weights exist offline (models/*.h5 are git-ignored upstream and h5py is absent), so the
+No trained weights exist offline (models/*.h5 are git-ignored upstream), so by default the
 network is random-initialised: it exercises the dense-contraction path (MIOpen convolutions on the
 matrix cores: bf16 weights, channels-last, batch norms folded) and the adapter into `Predictor._segmentLoad`, but its masks
-are not comparable with the reference's.  `load_state_dict` takes converted weights when they exist.
+are not comparable with the reference's.  `load_matterport_weights` converts a trained Keras weight file of that
+network (the `.h5` PixelLib / Matterport write, training/models.py:180-324 picks one) into this module's state_dict.
 The dense work is the only part of the prediction path where MFMA is the right tool; everything after
 it (FK, raster, loss) is the hand-written HIP engine.
 """
@@ -60,7 +61,9 @@ class _Bottleneck(nn.Module):
 class _ResNet(nn.Module):
     def __init__(self, blocks=(3, 4, 23, 3)):       # resnet101
         super().__init__()
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3), _bn(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
+        # Keras MaxPooling2D((3,3), strides 2, 'same') on an even-sized map pads one row/column at the END only
+        # (TensorFlow's SAME rule), so the windows start at 0 — not at -1 as MaxPool2d(padding=1) would have them
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3), _bn(64), nn.ReLU(), nn.ConstantPad2d((0, 1, 0, 1), 0.0), nn.MaxPool2d(3, 2))
         stages, cin = [], 64
         for i, (n, mid) in enumerate(zip(blocks, (64, 128, 256, 512))):
             layers = [_Bottleneck(cin, mid, 1 if i == 0 else 2, True)]
@@ -339,6 +342,94 @@ class MaskRCNN(nn.Module):
         inside = (Y > y1[:, None, None]) & (Y < y2[:, None, None]) & (X > x1[:, None, None]) & (X < x2[:, None, None])
         masks = ((val >= 0.5) & inside).permute(1, 2, 0).contiguous()
         return det_cls.cpu(), det_score.cpu(), masks.cpu()
+
+
+def matterport_layer_map(num_classes: int = 7) -> dict:
+    """state_dict module prefix -> (Keras layer name, kind) for Matterport's resnet101 Mask R-CNN (mrcnn/model.py:
+    resnet_graph, fpn, build_rpn_model, fpn_classifier_graph, build_fpn_mask_graph)."""
+    m = {'backbone.stem.0': ('conv1', 'conv'), 'backbone.stem.1': ('bn_conv1', 'bn')}
+    for s, n in enumerate((3, 4, 23, 3)):
+        for b in range(n):
+            blk = 'abcdefghijklmnopqrstuvwxyz'[b]                # stage 4 of resnet101: 'a', then chr(98 + i) = 'b'..'w'
+            tag = f'{s + 2}{blk}'
+            pre = f'backbone.stages.{s}.{b}'
+            for j, br in enumerate(('2a', '2b', '2c')):
+                m[f'{pre}.c{j + 1}'] = (f'res{tag}_branch{br}', 'conv')
+                m[f'{pre}.b{j + 1}'] = (f'bn{tag}_branch{br}', 'bn')
+            if b == 0:
+                m[f'{pre}.short.0'] = (f'res{tag}_branch1', 'conv')
+                m[f'{pre}.short.1'] = (f'bn{tag}_branch1', 'bn')
+    for i in range(4):
+        m[f'fpn.lat.{i}'] = (f'fpn_c{i + 2}p{i + 2}', 'conv')
+        m[f'fpn.smooth.{i}'] = (f'fpn_p{i + 2}', 'conv')
+    m.update({'rpn.shared': ('rpn_conv_shared', 'conv'), 'rpn.cls': ('rpn_class_raw', 'conv'), 'rpn.box': ('rpn_bbox_pred', 'conv'),
+              'head.0': ('mrcnn_class_conv1', 'conv'), 'head.1': ('mrcnn_class_bn1', 'bn'),
+              'head.3': ('mrcnn_class_conv2', 'conv'), 'head.4': ('mrcnn_class_bn2', 'bn'),
+              'cls': ('mrcnn_class_logits', 'dense'), 'box': ('mrcnn_bbox_fc', 'dense'),
+              'mask.12': ('mrcnn_mask_deconv', 'deconv'), 'mask.14': ('mrcnn_mask', 'conv')})
+    for i in range(4):
+        m[f'mask.{3 * i}'] = (f'mrcnn_mask_conv{i + 1}', 'conv')
+        m[f'mask.{3 * i + 1}'] = (f'mrcnn_mask_bn{i + 1}', 'bn')
+    return m
+
+
+def keras_to_torch(kind: str, var: str, value: np.ndarray) -> np.ndarray:
+    """One Keras variable in torch's layout.  Conv2D kernels are (kh, kw, in, out) -> (out, in, kh, kw); Conv2DTranspose
+    kernels (kh, kw, out, in) -> ConvTranspose2d's (in, out, kh, kw) — the same axis permutation, no flip: both
+    frameworks define the op as the gradient of their cross-correlation; Dense kernels (in, out) -> (out, in)."""
+    if var == 'kernel':
+        return np.ascontiguousarray(value.T if kind == 'dense' else value.transpose(3, 2, 0, 1))
+    return np.ascontiguousarray(value)
+
+
+_KERAS_VARS = {'conv': (('weight', 'kernel'), ('bias', 'bias')), 'deconv': (('weight', 'kernel'), ('bias', 'bias')),
+               'dense': (('weight', 'kernel'), ('bias', 'bias')),
+               'bn': (('weight', 'gamma'), ('bias', 'beta'), ('running_mean', 'moving_mean'), ('running_var', 'moving_variance'))}
+
+
+def load_matterport_weights(path: str, num_classes: int = 7) -> dict:
+    """A Keras `save_weights` HDF5 file of Matterport's Mask R-CNN (what PixelLib trains and loads: predict.py:96-98,
+    train.py:49) -> state_dict of `MaskRCNN(num_classes)`.
+
+    Keras keeps every variable as a dataset `<layer>/<scope>/<var>:0`, possibly below a `model_weights` group and, for
+    the RPN, below the nested `rpn_model`; only the last two path components identify a variable, so the file is walked
+    and indexed by `<scope>/<var>`.  Missing layers and shape mismatches (e.g. a head trained for another class count)
+    raise with the layer's name."""
+    try:
+        import h5py
+        f, found = h5py.File(path, 'r'), {}
+        f.visititems(lambda n, o: found.__setitem__(n, o) if isinstance(o, h5py.Dataset) else None)
+        read = lambda n: np.asarray(found[n])
+        names = list(found)
+    except ImportError:
+        from .data.hdf5 import H5File
+        f = H5File(path)
+        names = list(f.walk())
+        read = lambda n: np.asarray(f[n])
+    index = {}
+    for n in names:
+        parts = n.split('/')
+        if len(parts) >= 2:
+            index[f"{parts[-2]}/{parts[-1].split(':')[0]}"] = n
+    ref = MaskRCNN(num_classes).state_dict()
+    out = {k: v for k, v in ref.items() if k.endswith('num_batches_tracked')}
+    for prefix, (layer, kind) in matterport_layer_map(num_classes).items():
+        for tname, kname in _KERAS_VARS[kind]:
+            key = f'{layer}/{kname}'
+            if key not in index:
+                f.close()
+                raise KeyError(f"{path}: no '{key}' (layer {layer} of the Matterport Mask R-CNN); is this a resnet101 weight file?")
+            value = keras_to_torch(kind, kname, read(index[key]).astype(np.float32))
+            want = tuple(ref[f'{prefix}.{tname}'].shape)
+            if value.shape != want:
+                f.close()
+                raise ValueError(f"{path}: {key} has shape {value.shape} here, the network wants {want}"
+                                 + (f" (trained for another number of classes than {num_classes}?)" if layer.startswith('mrcnn_') else ''))
+            out[f'{prefix}.{tname}'] = torch.from_numpy(value)
+    f.close()
+    missing = set(ref) - set(out)
+    assert not missing, missing
+    return out
 
 
 class MaskRCNNSegmenter:

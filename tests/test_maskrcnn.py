@@ -103,3 +103,89 @@ def test_batched_trunk_gives_the_single_frame_results():
     ahead.announce([a, b])
     assert np.array_equal(ahead(b)['class_ids'], rb_['class_ids']) and not ahead._store.get(ahead._key(b))
     assert np.array_equal(ahead(b)['class_ids'], rb_['class_ids'])      # not stored any more: segmented on the spot
+
+
+def test_keras_layouts_mean_the_same_operation():
+    """keras_to_torch: the converted weight computes what Keras computes with the original (Conv2D 'valid', HWIO kernel;
+    Conv2DTranspose 2x2 stride 2, (kh, kw, out, in) kernel; Dense (in, out))."""
+    import torch.nn.functional as F
+    from rope_s3d_amd.maskrcnn import keras_to_torch
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(5, 6, 3))                                        # H, W, C as Keras sees a feature map
+    k = rng.normal(size=(3, 2, 3, 4))                                     # kh, kw, in, out
+    want = np.zeros((3, 5, 4))
+    for y in range(3):
+        for xx in range(5):
+            want[y, xx] = np.einsum('abi,abio->o', x[y:y + 3, xx:xx + 2], k)
+    got = F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None], torch.from_numpy(keras_to_torch('conv', 'kernel', k)))[0].permute(1, 2, 0)
+    assert np.allclose(got.numpy(), want)
+    kt = rng.normal(size=(2, 2, 4, 3))                                    # kh, kw, out, in
+    want = np.zeros((10, 12, 4))
+    for i in range(5):
+        for j in range(6):
+            for a in range(2):
+                for b in range(2):
+                    want[2 * i + a, 2 * j + b] = kt[a, b] @ x[i, j]
+    got = F.conv_transpose2d(torch.from_numpy(x).permute(2, 0, 1)[None], torch.from_numpy(keras_to_torch('deconv', 'kernel', kt)), stride=2)[0].permute(1, 2, 0)
+    assert np.allclose(got.numpy(), want)
+    kd = rng.normal(size=(3, 4))
+    assert np.allclose(F.linear(torch.from_numpy(x), torch.from_numpy(keras_to_torch('dense', 'kernel', kd))).numpy(), x @ kd)
+    assert keras_to_torch('bn', 'gamma', kd[0]) is not kd[0] and np.array_equal(keras_to_torch('bn', 'gamma', kd[0]), kd[0])
+
+
+def test_stem_pooling_has_tensorflow_same_alignment():
+    """Keras MaxPooling2D(3, strides 2, 'same') on an even map: windows [2i, 2i+2], the pad sits at the end."""
+    net = MaskRCNN(7)
+    pool = torch.nn.Sequential(*list(net.backbone.stem)[3:])
+    x = torch.rand(1, 2, 8, 10)
+    want = torch.zeros(1, 2, 4, 5)
+    for i in range(4):
+        for j in range(5):
+            want[..., i, j] = x[..., 2 * i:2 * i + 3, 2 * j:2 * j + 3].amax((-1, -2))
+    assert torch.equal(pool(x), want)
+
+
+def test_matterport_weight_file_round_trip(tmp_path):
+    """load_matterport_weights on a Keras-layout file (variables at <layer>/<scope>/<var>:0, the RPN nested in rpn_model,
+    everything under model_weights as model.save() puts it): every tensor of the network comes back, in torch layout."""
+    from rope_s3d_amd.data import hdf5
+    from rope_s3d_amd.maskrcnn import load_matterport_weights, matterport_layer_map
+    if not hdf5.available():
+        pytest.skip("no libhdf5 on this machine")
+    torch.manual_seed(3)
+    net = MaskRCNN(7)
+    for m in net.modules():                                               # running statistics away from their 0 / 1 defaults
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+    sd = net.state_dict()
+    lm = matterport_layer_map(7)
+    assert lm['backbone.stages.2.22.c3'] == ('res4w_branch2c', 'conv') and lm['backbone.stages.3.0.short.1'] == ('bn5a_branch1', 'bn')
+    assert lm['fpn.lat.3'] == ('fpn_c5p5', 'conv') and lm['mask.12'] == ('mrcnn_mask_deconv', 'deconv')
+    names = {'weight': {'conv': 'kernel', 'deconv': 'kernel', 'dense': 'kernel', 'bn': 'gamma'}, 'bias': {'bn': 'beta'},
+             'running_mean': {'bn': 'moving_mean'}, 'running_var': {'bn': 'moving_variance'}}
+    arrays = {}
+    for key, t in sd.items():
+        prefix, var = key.rsplit('.', 1)
+        if var == 'num_batches_tracked':
+            continue
+        layer, kind = lm[prefix]
+        v = t.numpy()
+        if var == 'weight' and kind in ('conv', 'deconv'):
+            v = v.transpose(2, 3, 1, 0)                                   # OIHW -> HWIO; (in, out, kh, kw) -> (kh, kw, out, in)
+        elif var == 'weight' and kind == 'dense':
+            v = v.T
+        outer = 'rpn_model' if layer.startswith('rpn_') else layer
+        arrays[f"model_weights/{outer}/{layer}/{names[var].get(kind, var)}:0"] = v
+    path = hdf5.write_arrays(str(tmp_path / 'mask_rcnn_model.h5'), arrays, {'backend': 'tensorflow', 'keras_version': '2.4.0'})
+    got = load_matterport_weights(path, 7)
+    assert set(got) == set(sd)
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    MaskRCNN(7).load_state_dict(got)                                      # strict
+    with pytest.raises(ValueError, match='another number of classes'):
+        load_matterport_weights(path, 5)
+    del arrays['model_weights/res3b_branch2b/res3b_branch2b/kernel:0']
+    path2 = hdf5.write_arrays(str(tmp_path / 'broken.h5'), arrays)
+    with pytest.raises(KeyError, match='res3b_branch2b/kernel'):
+        load_matterport_weights(path2, 7)
