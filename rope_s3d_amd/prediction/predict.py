@@ -14,6 +14,7 @@ from typing import Callable, Optional
 
 import numpy as np
 
+from ..config import Paths
 from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
 from ..crop import Crop
 from ..engine import (LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, StageDesc,
@@ -137,13 +138,24 @@ class Predictor:
         if self.synthetic:
             self.color_dict = color_dict
         else:
-            self.seg = segmenter
             self.model_ds = model_ds
+            self.seg = segmenter if segmenter is not None else self._load_segmenter(model_ds, device)
         self._lookup_divisions = lookup_divisions
         self.lookup_table_budget = int(lookup_table_budget)
         self.camera_pose = None
         self.changeCameraPose(camera_pose)
         self.evaluations = 0          # candidates rendered+scored, for throughput accounting
+
+    def _load_segmenter(self, model_ds: str, device: int):
+        """The reference's default: the newest model trained on `model_ds` (ModelManager().dynamicLoad(dataset=model_ds),
+        predict.py:94-98), as the torch Mask R-CNN with those weights.  None when no trained model is on disk — run()
+        then asks for a segmenter instead of guessing."""
+        from ..models import ModelManager
+        path = ModelManager().dynamicLoad(dataset=model_ds)
+        if path is None:
+            return None
+        from ..maskrcnn import MaskRCNNSegmenter, load_matterport_weights
+        return MaskRCNNSegmenter(len(self.classes), device=f'cuda:{device}', state_dict=load_matterport_weights(path, len(self.classes)))
 
     # ------------------------------------------------------------------ camera / lookup grid
     def changeCameraPose(self, camera_pose):
@@ -249,8 +261,9 @@ class Predictor:
         """Segmentation path (predict.py:415-442).  NB: like the reference, zeroes target_depth in place."""
         if self.seg is None:
             raise NotImplementedError(
-                "no segmenter: pass segmenter=callable(colour)->{'class_ids','scores','masks'} (the Mask R-CNN "
-                "stage on PyTorch-ROCm is SURVEY §8f rank 1), or color_dict for synthetic input")
+                f"no trained segmentation model for '{self.model_ds}' under {Paths().MODELS} and no segmenter given: pass "
+                "segmenter=callable(colour)->{'class_ids','scores','masks'} (e.g. rope_s3d_amd.maskrcnn.MaskRCNNSegmenter), "
+                "or color_dict for synthetic input")
         small = self._downsample(target_color, self.ds_factor)
         r = self.seg(small)
         seg = self._reorganize_by_link(r)

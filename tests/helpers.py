@@ -66,3 +66,31 @@ def slu_grid(limits: np.ndarray, d: int) -> np.ndarray:
         tile = num // (repeat * divs[idx])
         ang[:, idx] = np.tile(np.repeat(rng, repeat), tile)
     return ang
+
+
+def keras_arrays(state_dict, num_classes: int = 7) -> dict:
+    """A MaskRCNN state_dict as the variables of a Keras weight file: <layer>/<scope>/<var>:0 below model_weights (as
+    model.save() nests them), the RPN inside rpn_model, kernels in Keras layouts."""
+    from rope_s3d_amd.maskrcnn import matterport_layer_map
+    lm = matterport_layer_map(num_classes)
+    names = {'weight': {'conv': 'kernel', 'deconv': 'kernel', 'dense': 'kernel', 'bn': 'gamma'}, 'bias': {'bn': 'beta'},
+             'running_mean': {'bn': 'moving_mean'}, 'running_var': {'bn': 'moving_variance'}}
+    arrays = {}
+    for key, t in state_dict.items():
+        prefix, var = key.rsplit('.', 1)
+        if var == 'num_batches_tracked':
+            continue
+        layer, kind = lm[prefix]
+        v = t.numpy()
+        if var == 'weight' and kind in ('conv', 'deconv'):
+            v = v.transpose(2, 3, 1, 0)                                   # OIHW -> HWIO; (in, out, kh, kw) -> (kh, kw, out, in)
+        elif var == 'weight' and kind == 'dense':
+            v = v.T
+        outer = 'rpn_model' if layer.startswith('rpn_') else layer
+        arrays[f"model_weights/{outer}/{layer}/{names[var].get(kind, var)}:0"] = v
+    return arrays
+
+
+def write_keras_weights(state_dict, path: str, num_classes: int = 7) -> str:
+    from rope_s3d_amd.data import hdf5
+    return hdf5.write_arrays(path, keras_arrays(state_dict, num_classes), {'backend': 'tensorflow', 'keras_version': '2.4.0'})

@@ -391,3 +391,36 @@ def test_reference_hdf5_dataset_round_trip(tmp_path):
     (tmp_path / 'bad' / 'bad.h5').write_bytes(b'not an hdf5 file')
     with pytest.raises(IOError):
         Dataset(str(tmp_path / 'bad'))
+
+
+def test_model_manager_selection_rules(tmp_path):
+    """ModelManager.dynamicLoad / loadByID (training/models.py:180-324): what Predictor(model_ds=...) loads by default."""
+    import json
+    from rope_s3d_amd.models import ModelManager
+
+    def model(mid, dataset, size, train, date, epochs, classes=('BG', 'a')):
+        d = tmp_path / 'models' / mid
+        d.mkdir(parents=True)
+        (d / 'ModelData.json').write_text(json.dumps({'id': mid, 'dataset': dataset, 'dataset_size': size, 'train_size': train,
+                                                      'valid_size': size - train, 'classes': list(classes), 'date_trained': date,
+                                                      'unknown_key': 1}))
+        for e in epochs:
+            (d / f'mask_rcnn_model.{e:03d}-0.{e}00.h5').write_bytes(b'')
+        return d
+    assert ModelManager(str(tmp_path / 'models')).dynamicLoad(dataset='set10') is None          # nothing trained yet
+    model('AAAA', 'set10', 100, 80, '2021-03-01 10:00:00.000000', [5, 12, 9])
+    model('BBBB', 'set10', 100, 50, '2021-04-01 10:00:00.000000', [30])
+    model('CCCC', 'set20', 400, 300, '2021-02-01 10:00:00.000000', [2], classes=('BG', 'b'))
+    mm = ModelManager(str(tmp_path / 'models'))
+    assert mm.num_total == 3 and mm.info['AAAA'].epochs_trained == 12 and mm.info['AAAA'].train_ratio == 0.8
+    assert mm.loadByID('AAAA').endswith('AAAA/mask_rcnn_model.012-0.1200.h5')                    # last checkpoint by name
+    assert '/BBBB/' in mm.dynamicLoad(dataset='set10')                                           # two match: most recently trained
+    assert '/CCCC/' in mm.dynamicLoad(dataset='set20') and '/CCCC/' in mm.dynamicLoad(classes=['BG', 'b'])
+    assert '/BBBB/' in mm.dynamicLoad(dataset='set99')                                           # unsatisfiable: dropped, newest overall
+    assert '/AAAA/' in mm.dynamicLoad(dataset='set10', train_size=75)                            # closest
+    assert '/CCCC/' in mm.dynamicLoad(train_size=np.inf) and '/BBBB/' in mm.dynamicLoad(train_size=-np.inf)
+    assert '/AAAA/' in mm.dynamicLoad(dataset='set10', epochs_trained_below=20)
+    assert '/CCCC/' in mm.dynamicLoad(dataset_size_above=1000)                                   # nothing above: the maximum
+    assert '/AAAA/' in mm.dynamicLoad({'dataset': 'set10'}, train_ratio=0.8)
+    with pytest.raises(AssertionError, match='Unknown kwarg'):
+        mm.dynamicLoad(colour='red')

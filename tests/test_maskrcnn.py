@@ -5,6 +5,8 @@ import torch
 
 from rope_s3d_amd.maskrcnn import MaskRCNN, MaskRCNNSegmenter, _nms, _pyramid_anchors, _roi_align
 
+import helpers
+
 
 def test_anchor_pyramid_and_parameter_count():
     a = _pyramid_anchors(512, 'cpu')
@@ -162,22 +164,8 @@ def test_matterport_weight_file_round_trip(tmp_path):
     lm = matterport_layer_map(7)
     assert lm['backbone.stages.2.22.c3'] == ('res4w_branch2c', 'conv') and lm['backbone.stages.3.0.short.1'] == ('bn5a_branch1', 'bn')
     assert lm['fpn.lat.3'] == ('fpn_c5p5', 'conv') and lm['mask.12'] == ('mrcnn_mask_deconv', 'deconv')
-    names = {'weight': {'conv': 'kernel', 'deconv': 'kernel', 'dense': 'kernel', 'bn': 'gamma'}, 'bias': {'bn': 'beta'},
-             'running_mean': {'bn': 'moving_mean'}, 'running_var': {'bn': 'moving_variance'}}
-    arrays = {}
-    for key, t in sd.items():
-        prefix, var = key.rsplit('.', 1)
-        if var == 'num_batches_tracked':
-            continue
-        layer, kind = lm[prefix]
-        v = t.numpy()
-        if var == 'weight' and kind in ('conv', 'deconv'):
-            v = v.transpose(2, 3, 1, 0)                                   # OIHW -> HWIO; (in, out, kh, kw) -> (kh, kw, out, in)
-        elif var == 'weight' and kind == 'dense':
-            v = v.T
-        outer = 'rpn_model' if layer.startswith('rpn_') else layer
-        arrays[f"model_weights/{outer}/{layer}/{names[var].get(kind, var)}:0"] = v
-    path = hdf5.write_arrays(str(tmp_path / 'mask_rcnn_model.h5'), arrays, {'backend': 'tensorflow', 'keras_version': '2.4.0'})
+    path = helpers.write_keras_weights(sd, str(tmp_path / 'mask_rcnn_model.h5'))
+    arrays = helpers.keras_arrays(sd)
     got = load_matterport_weights(path, 7)
     assert set(got) == set(sd)
     for k in sd:
@@ -189,3 +177,37 @@ def test_matterport_weight_file_round_trip(tmp_path):
     path2 = hdf5.write_arrays(str(tmp_path / 'broken.h5'), arrays)
     with pytest.raises(KeyError, match='res3b_branch2b/kernel'):
         load_matterport_weights(path2, 7)
+
+
+@pytest.mark.gpu
+def test_predictor_loads_the_trained_model_of_its_dataset(tmp_path):
+    """Predictor(model_ds=...) without a segmenter: the newest model trained on that dataset is found under MODELS
+    (ModelManager.dynamicLoad, predict.py:94-98), its Keras checkpoint is converted, and frames go through it."""
+    import json
+    from rope_s3d_amd.data import hdf5
+    if not hdf5.available():
+        pytest.skip("no libhdf5 on this machine")
+    from rope_s3d_amd import Predictor, SyntheticPredictor
+    from rope_s3d_amd.config import Paths
+    from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
+    torch.cuda.init()
+    torch.manual_seed(1)
+    folder = tmp_path / 'models' / 'QXZV'
+    folder.mkdir(parents=True)
+    (folder / 'ModelData.json').write_text(json.dumps({'id': 'QXZV', 'dataset': 'set10', 'dataset_size': 10, 'train_size': 8, 'valid_size': 2,
+                                                       'classes': ['BG'], 'date_trained': '2021-03-01 10:00:00.000000'}))
+    want = MaskRCNN(7).state_dict()
+    helpers.write_keras_weights(want, str(folder / 'mask_rcnn_model.007-0.120.h5'))
+    old = Paths().MODELS
+    Paths().set('MODELS', str(tmp_path / 'models'))
+    try:
+        p = Predictor(DEFAULT_CAMERA_POSE, 4, base_intrin='640_480_color', model_ds='set10', lookup_divisions=4)
+        none = Predictor(DEFAULT_CAMERA_POSE, 4, base_intrin='640_480_color', model_ds='set10', lookup_divisions=4, segmenter=lambda c: None)
+    finally:
+        Paths().set('MODELS', old)
+    assert isinstance(p.seg, MaskRCNNSegmenter) and not isinstance(none.seg, MaskRCNNSegmenter)
+    sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '640_480_color', 4, 'SLU', noise=False, seed=2, lookup_divisions=4)
+    sp.renderer.setJointAngles([0.3, 0.2, 0.5, 0, 0, 0])
+    color, depth = sp.renderer.render()
+    out = p.run(color, depth.astype(np.float64))
+    assert out.shape == (6,) and np.isfinite(out).all()
