@@ -1,0 +1,110 @@
+"""rope_predict.cpp without a GPU: the stage loop is host code over the C ABI, so here its rope_eval calls are answered
+by the CPU oracle (tests/native_shim.cpp) and its decisions are compared, stage by stage, with the sequential
+restatement of the reference (oracle/predictor_ref.py).  The -m gpu suite repeats this with the real engine."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import predictor_ref
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, LINK_BLUE
+from rope_s3d_amd.crop import crop_pose_grid
+from rope_s3d_amd.engine import STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, PredictArgs, StageDesc
+
+import helpers
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+THREADS = min(os.cpu_count() or 1, 8)
+NAN = float('nan')
+
+
+@pytest.fixture(scope='module')
+def shim(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp('shim') / 'libpredict_shim.so')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-ffp-contract=off', '-fPIC', '-shared',
+                           os.path.join(ROOT, 'rope_s3d_amd', 'csrc', 'rope_predict.cpp'), os.path.join(ROOT, 'tests', 'native_shim.cpp'), '-o', out])
+    lib = C.CDLL(out)
+    lib.rope_predict.argtypes = [C.c_void_p, C.POINTER(PredictArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.shim_last_error.restype = C.c_char_p
+    return lib
+
+
+def _stages(do_angles):
+    def desc(kind, n, count=0, joints='', init=None, redux=0.5, stop=0.01, rng=NAN):
+        d = StageDesc(kind, n, count, sum(1 << 'SLURBT'.index(c) for c in joints))
+        d.init_rate[:] = [NAN if r is None else r for r in (init or [None] * 6)]
+        d.rate_reduction, d.early_stop, d.range = redux, stop, rng
+        return d
+    if do_angles == 'SL':        # stages.py:138-150
+        return [desc(STAGE_LOOKUP, 6), desc(STAGE_SFLIP, 4), desc(STAGE_ISWEEP, 4, 10, 'L', rng=0.1), desc(STAGE_ISWEEP, 4, 10, 'S', rng=0.1),
+                desc(STAGE_SFLIP, 4)]
+    return [desc(STAGE_LOOKUP, 6), desc(STAGE_SFLIP, 4), desc(STAGE_DESCENT, 4, 10, 'SL', [0.05, 0.05, 0.1, 0.5, 0.5, 0.5], stop=0.1),
+            desc(STAGE_SFLIP, 4), desc(STAGE_ISWEEP, 6, 25, 'U'), desc(STAGE_SFLIP, 4), desc(STAGE_SFLIP, 6), desc(STAGE_ISWEEP, 6, 10, 'U', rng=0.1),
+            desc(STAGE_DESCENT, 6, 40, 'SLU', stop=0.0075)]          # stages.py:152-168
+
+
+@pytest.mark.parametrize('do_angles,seed,speculate', [('SLU', 7919, 3), ('SLU', 7920, 1), ('SL', 7921, 3)])
+def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculate):
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    intr, PV = helpers.camera('640_480_color', ds=8, as_predictor=True)          # 80x60: the oracle renders ~500 poses per run
+    o = helpers.make_oracle(rb, intr, PV)
+    q_true = np.random.default_rng(seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    depth, ids = o.render(q_true, 6)
+    tq, t32, flags, tgt, _, _ = helpers.synthetic_target(depth, ids)
+    blue = np.where(ids == 255, 0, np.asarray(LINK_BLUE)[np.minimum(ids, 5)]).astype(np.uint8)
+    grid = helpers.slu_grid(lim, 4)
+    cover = o.coverage(crop_pose_grid(lim, intr.size, 6)[0], 6, threads=THREADS) != 0
+    r, c = np.where(cover)
+    crop = np.array([max(r.min() - 10, 0), min(r.max() + 10, intr.height - 1), max(c.min() - 10, 0), min(c.max() + 10, intr.width - 1)], np.int32)
+    names = rb.link_names
+    want, trace, n_eval = predictor_ref.predict_reference(o, tgt, blue, names, {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}, lim,
+                                                          DEFAULT_CAMERA_POSE, grid, crop, do_angles)
+    calls = []
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32))
+    def answer(cand, n, n_render, loss, crop_p, err_out, best_idx):
+        rows = np.ctypeslib.as_array(cand, (n, 6)).copy()
+        calls.append(n)
+        if loss == orc.LOSS_LOOKUP:
+            err = o.eval(rows, loss, n_render, tq, t32, np.ctypeslib.as_array(crop_p, (4,)), flags, threads=THREADS)
+        else:
+            err = o.eval(rows, loss, n_render, tq, link_flags=flags, threads=THREADS)
+        if err_out:
+            np.ctypeslib.as_array(err_out, (n,))[:] = err
+        if best_idx:
+            best_idx[0] = int(np.argmin(np.where(np.isnan(err), np.inf, err)))
+        return 0
+    shim.shim_set_callback(answer)
+    stages = _stages(do_angles)
+    arr = (StageDesc * len(stages))(*stages)
+    limits, cam, inc = np.ascontiguousarray(lim, np.float64), np.asarray(DEFAULT_CAMERA_POSE, np.float64), np.array([.005] * 6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    args = PredictArgs(arr, len(arr), speculate, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop))
+    out, got_trace, n = np.empty(6), np.empty((len(arr), 6)), C.c_int64()
+    rc = shim.rope_predict(C.c_void_p(1), C.byref(args), p(out), p(got_trace), C.byref(n))
+    assert rc == 0, shim.shim_last_error()
+    assert len(trace) == len(stages)
+    for k, (kind, ang) in enumerate(trace):
+        assert np.array_equal(got_trace[k], ang), (k, kind, got_trace[k], ang)
+    assert np.array_equal(out, want)
+    if speculate == 1:
+        # the serial order asks for exactly the reference's renders, minus the lower-limit render SFlip throws away
+        assert n_eval - 4 <= n.value <= n_eval
+    assert calls[0] == len(grid) and max(calls[1:]) <= 26          # the lookup grid, then batches of at most 1 + 25 poses
+
+
+def test_argument_checks_without_an_engine(shim):
+    lim = np.ascontiguousarray(helpers.robot().joint_limits, np.float64)
+    cam, inc = np.asarray(DEFAULT_CAMERA_POSE, np.float64), np.array([.005] * 6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = np.empty(6)
+    for stage, text in ((StageDesc(STAGE_ISWEEP, 6, 3, 4), b'at least 4 divisions'), (StageDesc(STAGE_LOOKUP, 6), b'needs the pose grid'),
+                        (StageDesc(7, 6), b'unknown stage kind'), (StageDesc(STAGE_SFLIP, 9), b'to_render must be 1..6')):
+        arr = (StageDesc * 1)(stage)
+        args = PredictArgs(arr, 1, 3, p(lim), p(cam), p(inc), None, 0, 0, None)
+        assert shim.rope_predict(C.c_void_p(1), C.byref(args), p(out), None, None) == -1
+        assert text in shim.shim_last_error()
