@@ -58,6 +58,22 @@ int rope_set_robot(rope_ctx *ctx, const uint32_t *ml_header, int n_meshlets, con
                    int n_ml_verts, const uint32_t *ml_tris, int n_ml_tris, const int32_t *link_first,
                    int n_links, const double *joint_fixed, const double *joint_axes);
 
+/* The same from plain meshes: partitions every link into meshlets on the host (rope_partition_mesh), builds the
+ * arrays above and calls rope_set_robot — everything MeshLoader.load + from_trimesh leave to pyrender
+ * (render_utils.py:22-41), for hosts that are not Python.
+ *   verts    V x 3 float32, welded link meshes concatenated (link frame, metres)
+ *   faces    T x 3 int32, vertex indices LOCAL to the triangle's link
+ *   vtx_off / tri_off   n_links+1 offsets of every link into verts / faces */
+int rope_set_robot_mesh(rope_ctx *ctx, const float *verts, const int32_t *faces, const int32_t *vtx_off, const int32_t *tri_off,
+                        int n_links, const double *joint_fixed, const double *joint_axes);
+
+/* One mesh -> surface patches of <= max_tris (<= 128) triangles over <= max_verts (<= 64) vertices.  Host only: no
+ * context, no GPU.  tri_order receives the n_tris triangle ids grouped by patch, meshlet_first (n_tris+1 entries
+ * available) the offsets of the patches into it; returns the number of patches or ROPE_E_ARG.  Any partition renders
+ * the same image; this one keeps patches compact on the surface (small screen boxes). */
+int rope_partition_mesh(const float *verts, int n_verts, const int32_t *faces, int n_tris, int max_tris, int max_verts,
+                        int32_t *tri_order, int32_t *meshlet_first);
+
 /* Camera: PV = P·V (4x4 row-major doubles), image size and clip planes.
  * Replaces Renderer.setCameraPose (render.py:107-111) + Intrinsics.pyrender_camera
  * (projection.py:161-169) + pyrender.OffscreenRenderer(W,H) (render.py:60). */

@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip',
-    'rope_set_frames', 'rope_eval_views', 'rope_predict')
+    'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP = 0, 1, 2, 3
@@ -86,6 +86,8 @@ def load_library(path: str = None):
     lib.rope_profile_eval.argtypes = [vp, i32, i32, vp, i32, vp]
     lib.rope_debug_skip.argtypes = [vp, i32]
     lib.rope_predict.argtypes = [vp, C.POINTER(PredictArgs), vp, vp, C.POINTER(C.c_int64)]
+    lib.rope_set_robot_mesh.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.rope_partition_mesh.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
     lib.rope_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
     _lib = lib
@@ -153,6 +155,15 @@ class Engine:
         self._check(self._lib.rope_set_robot(self._ctx, _p(hdr), len(hdr), _p(verts), len(verts), _p(tris), len(tris),
                                              _p(first), len(first) - 1, _p(jf), _p(ja)), 'rope_set_robot')
         self.n_links = len(first) - 1
+
+    def set_robot_mesh(self, robot: RobotModel):
+        """rope_set_robot_mesh: plain vertex / index arrays in, the library builds the meshlets (what a C host calls)."""
+        verts, faces = np.ascontiguousarray(robot.verts, np.float32), np.ascontiguousarray(robot.faces, np.int32)
+        vo, to = np.ascontiguousarray(robot.vtx_off, np.int32), np.ascontiguousarray(robot.tri_off, np.int32)
+        jf, ja = np.ascontiguousarray(robot.joint_fixed, np.float64), np.ascontiguousarray(robot.joint_axes, np.float64)
+        self._check(self._lib.rope_set_robot_mesh(self._ctx, _p(verts), _p(faces), _p(vo), _p(to), len(vo) - 1, _p(jf), _p(ja)),
+                    'rope_set_robot_mesh')
+        self.n_links = len(vo) - 1
 
     def set_camera(self, PV: np.ndarray, W: int, H: int, znear: float, zfar: float):
         PV = np.ascontiguousarray(PV, np.float64)

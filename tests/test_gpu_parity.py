@@ -130,3 +130,34 @@ def test_small_batch_split_does_not_change_results(scene):
             assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
             ref = o.eval(cand[:n_c], loss, n, tq, t32, None, flags, threads=4)
             assert np.array_equal(err_a.view(np.uint64), ref.view(np.uint64))
+
+
+def test_robot_from_plain_meshes_gives_the_same_results(scene):
+    """rope_set_robot_mesh (meshlets built inside the library from vertex / index arrays, as a C host would call it)
+    against the default path and the Python partitioner: the image does not depend on the partition."""
+    import os
+    from rope_s3d_amd import engine as eng
+    from rope_s3d_amd.robot import RobotModel
+    rb, intr, PV, o, e = scene[:5]
+    lim = rb.joint_limits
+    cand = np.random.default_rng(3).uniform(lim[:, 0], lim[:, 1], (24, 6))
+    q = cand[0]
+    depth, ids = e.render(q, 6)
+    tq = eng.pack_target(depth.astype(np.float64))
+    e.set_target(tq, None, np.zeros(8, np.uint8))
+    want_err, want_sums, _, _ = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+    os.environ['ROPE_MESHLET_BUILDER'] = 'grow'
+    try:
+        python_built = RobotModel.from_urdf()
+    finally:
+        del os.environ['ROPE_MESHLET_BUILDER']
+    for setter, model in ((e.set_robot_mesh, rb), (e.set_robot, python_built)):
+        setter(model)
+        try:
+            d2, i2 = e.render(q, 6)
+            assert np.array_equal(i2, ids) and np.array_equal(d2.view(np.uint32), depth.view(np.uint32))
+            e.set_target(tq, None, np.zeros(8, np.uint8))
+            err, sums, _, _ = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+            assert np.array_equal(sums, want_sums) and np.array_equal(err.view(np.uint64), want_err.view(np.uint64))
+        finally:
+            e.set_robot(rb)

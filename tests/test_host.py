@@ -424,3 +424,32 @@ def test_model_manager_selection_rules(tmp_path):
     assert '/AAAA/' in mm.dynamicLoad({'dataset': 'set10'}, train_ratio=0.8)
     with pytest.raises(AssertionError, match='Unknown kwarg'):
         mm.dynamicLoad(colour='red')
+
+
+def test_native_and_python_partitioners_agree_in_kind():
+    """rope_partition_mesh (csrc/rope_meshlets.cpp) and robot._grow_partition are the same region growing: both cover
+    every triangle once within the 128 / 64 limits and land on (nearly) the same patches; bad meshes are refused."""
+    import ctypes as C
+    from rope_s3d_amd.engine import load_library
+    from rope_s3d_amd.robot import _grow_partition, _native_partition
+    rb = helpers.robot()
+    l = 3
+    V = np.ascontiguousarray(rb.verts[rb.vtx_off[l]:rb.vtx_off[l + 1]])
+    F = np.ascontiguousarray(rb.faces[rb.tri_off[l]:rb.tri_off[l + 1]])
+    a, b = _native_partition(V, F, 128, 64), _grow_partition(V, F, 128, 64)
+    for part in (a, b):
+        assert np.array_equal(np.sort(np.concatenate(part)), np.arange(len(F)))
+        assert max(len(p) for p in part) <= 128 and max(len(np.unique(F[p])) for p in part) <= 64
+    assert abs(len(a) - len(b)) <= max(2, len(b) // 50)
+    key = lambda part: {tuple(sorted(p.tolist())) for p in part}
+    assert len(key(a) & key(b)) >= 0.8 * len(b)                      # the same patches but for distance ties and island folding
+    small = _native_partition(V, F, 32, 24)
+    assert max(len(p) for p in small) <= 32 and max(len(np.unique(F[p])) for p in small) <= 24 and len(small) > len(a)
+    lib = load_library()
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    order, first = np.empty(len(F), np.int32), np.empty(len(F) + 1, np.int32)
+    bad = F.copy(); bad[5, 1] = len(V)
+    assert lib.rope_partition_mesh(p(V), len(V), p(bad), len(F), 128, 64, p(order), p(first)) == -1
+    assert lib.rope_partition_mesh(p(V), len(V), p(F), len(F), 129, 64, p(order), p(first)) == -1
+    assert lib.rope_partition_mesh(p(V), len(V), p(F), len(F), 128, 65, p(order), p(first)) == -1
+    assert lib.rope_partition_mesh(p(V), len(V), p(F), 0, 128, 64, p(order), p(first)) == -1
