@@ -1,0 +1,65 @@
+"""examples/predict_frame.c: a plain-C host on the C ABI alone.  CPU: it builds against include/rope_s3d.h and
+librope_hip.so and fails loudly without a GPU.  GPU: its joint angles equal Predictor.run's, digit for digit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
+
+import helpers
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+@pytest.fixture(scope='module')
+def exe(tmp_path_factory):
+    from rope_s3d_amd import build
+    build.build()
+    out = str(tmp_path_factory.mktemp('chost') / 'predict_frame')
+    csrc = os.path.join(ROOT, 'rope_s3d_amd', 'csrc')
+    subprocess.check_call(['gcc', '-O2', '-Wall', '-Werror', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'predict_frame.c'),
+                           '-L' + csrc, '-lrope_hip', '-Wl,-rpath,' + csrc, '-Wl,-rpath-link,/opt/rocm/lib', '-lm', '-o', out])
+    return out
+
+
+def test_c_host_builds_and_refuses_to_run_without_a_gpu(exe, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    rb = helpers.robot()
+    files = {'verts.f32': rb.verts.astype(np.float32), 'faces.i32': rb.faces.astype(np.int32), 'vtx_off.i32': rb.vtx_off.astype(np.int32),
+             'tri_off.i32': rb.tri_off.astype(np.int32), 'joint_fixed.f64': rb.joint_fixed, 'joint_axes.f64': rb.joint_axes,
+             'PV.f64': np.eye(4), 'clip.f64': np.array([.05, 100.]), 'dims.i32': np.array([16, 12], np.int32), 'limits.f64': rb.joint_limits,
+             'camera_pose.f64': np.asarray(DEFAULT_CAMERA_POSE, float), 'tq.u64': np.zeros(192, np.uint64), 't32.f32': np.zeros(192, np.float32),
+             'flags.u8': np.zeros(8, np.uint8), 'grid.f64': np.zeros((8, 6)), 'crop.i32': np.array([0, 11, 0, 15], np.int32)}
+    for name, a in files.items():
+        np.ascontiguousarray(a).tofile(tmp_path / name)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and 'rope_create' in r.stderr and r.stdout == ''          # no device: says so, computes nothing
+    (tmp_path / 'tq.u64').write_bytes(b'\0' * 8)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'does not match' in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_predicts_the_same_angles_as_the_python_host(exe, tmp_path):
+    from dump_frame_bundle import dump_frame_bundle
+    from rope_s3d_amd import SyntheticPredictor
+    sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '640_480_color', 4, 'SLU', noise=False, seed=5, lookup_divisions=5)
+    p = sp.predictor
+    lim = helpers.robot().joint_limits
+    for seed in range(3):
+        q = np.random.default_rng(300 + seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+        sp.renderer.setJointAngles(q)
+        color, depth = sp.renderer.render()
+        want = p.run(color, depth)
+        bundle = dump_frame_bundle(str(tmp_path / f'bundle{seed}'), p, p.prepare(color, depth))
+        r = subprocess.run([exe, bundle], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        got = np.array([float(x) for x in r.stdout.split()])
+        assert np.array_equal(got, want), (got, want)
+        assert f'{p.evaluations}' != '' and 'candidate poses rendered and scored' in r.stderr
