@@ -52,21 +52,33 @@ def run(args):
         kwargs['color_dict'] = ds.attrs['color_dict']         # link masks are read from the colour render
     am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
                    do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
+    # Frames are independent, and one frame's ~25 short dependent batches leave the GPU idle between them: k Predictors
+    # (own context and stream each) fed by k threads fill those gaps (prediction/pool.py).  Not with a segmenter that keeps
+    # per-chunk state or a network on the GPU: that stage is the bottleneck then, and it is not written for several threads.
+    n_pred = max(1, int(getattr(args, 'predictors', 1) or 1))
+    pool = None
+    if n_pred > 1 and am.synthetic:
+        from rope_s3d_amd.prediction.pool import PredictorPool
+        pool = PredictorPool(n_pred - 1, ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
+                             do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
+        pool.predictors.insert(0, am)
 
     lo, hi = shard_range(ds.length, rank, world)
     out = np.zeros((hi - lo, 6))
     chunk = 200                                                 # the reference reads ~200 frames at a time (predict_dataset.py:27-41)
     for start in range(lo, hi, chunk):
         end = min(start + chunk, hi)
-        og_imgs = np.copy(ds.og_img[start:end])
-        dms = np.copy(ds.depthmaps[start:end])
+        # slices, not copies (predict_dataset.py:39-41 copies): an HDF5 slice is already a fresh array, and a memory-mapped
+        # one is read by the worker that needs it — with ds_factor 8 the down-sampling touches a third of its pages
+        og_imgs = ds.og_img[start:end]
+        dms = ds.depthmaps[start:end]
         cam_poses = np.copy(ds.camera_pose[start:end])
         seg = None if am.synthetic else getattr(am, 'seg', None)
         if hasattr(seg, 'announce'):                          # the chunk's frames through the network in batches of 8
             seg.announce([am._downsample(og_imgs[i], am.ds_factor) for i in range(end - start)])
         # frame by frame as predict_dataset.py:43-44, with the next frame's host preparation (down-sampling, masks,
         # segmentation) running beside the current frame's device work
-        out[start - lo:end - lo] = am.run_many(og_imgs, dms, cam_poses)
+        out[start - lo:end - lo] = (pool or am).run_many(og_imgs, dms, cam_poses)
     full = gather_rows(out, ds.length, device=device)
     if rank == 0:
         np.save(f'predictions_{os.path.basename(os.path.normpath(args.dataset))}.npy', full)
@@ -85,5 +97,7 @@ if __name__ == "__main__":
     parser.add_argument('-ds_factor', type=int, default=8, help="Downsampling factor (the reference hard-codes 8).")
     parser.add_argument('-segmenter', type=str, default=None, choices=[None, 'maskrcnn'],
                         help="'maskrcnn': segment every frame with the Mask R-CNN stage instead of reading a synthetic set's colours.")
+    parser.add_argument('-predictors', type=int, default=4,
+                        help="Predictors (engine contexts + threads) per GPU when the link masks come from the colour render; 1 = one frame at a time.")
     parser.add_argument('-weights', type=str, default=None, help="weights for -segmenter maskrcnn: the reference's trained Keras .h5 or a torch state_dict (random weights otherwise).")
     run(parser.parse_args())

@@ -440,3 +440,22 @@ def test_predict_dataset_reads_the_reference_hdf5_form(tmp_path, monkeypatch):
     got = pd.run(argparse.Namespace(dataset=os.path.dirname(h5), angs='SLU', ds_factor=4))
     assert np.array_equal(got, want)
     assert np.array_equal(np.load(tmp_path / 'predictions_synth3h.npy'), want)
+
+
+def test_predictor_pool_equals_one_predictor(synth):
+    """PredictorPool: three Predictors on one GPU fed by three threads give, frame by frame, what one Predictor gives."""
+    from rope_s3d_amd.prediction.pool import PredictorPool
+    p = synth.predictor
+    lim = helpers.robot().joint_limits
+    colors, depths = [], []
+    for seed in range(10):
+        q = np.random.default_rng(80 + seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+        synth.renderer.setJointAngles(q)
+        c, d = synth.renderer.render()
+        colors.append(c); depths.append(d)
+    want = np.array([p.run(c, d) for c, d in zip(colors, depths)])
+    pool = PredictorPool(3, DEFAULT_CAMERA_POSE, 4, base_intrin='640_480_color', color_dict=p.color_dict, lookup_divisions=4)
+    for _ in range(2):                                                  # twice: the contexts are reused across calls
+        assert np.array_equal(pool.run_many(colors, depths, [DEFAULT_CAMERA_POSE] * 10), want)
+    assert np.array_equal(pool.run_many(colors[:2], depths[:2]), want[:2]) and pool.run_many([], []).shape == (0, 6)
+    assert pool.evaluations > 0 and len(pool) == 3

@@ -36,7 +36,17 @@ for q in poses:
 p.evaluations = 0
 res = np.zeros((2, n, 6))
 t0 = time.perf_counter()
-if os.environ.get('ROPE_PREFETCH', '0') != '0':             # Predictor.run_many: frame i+1 prepared while frame i is on the GPU
+if int(os.environ.get('ROPE_POOL', '0')) > 1:                # PredictorPool: k Predictors / threads on this GPU
+    from rope_s3d_amd.prediction.pool import PredictorPool
+    pool = PredictorPool(int(os.environ['ROPE_POOL']), DEFAULT_CAMERA_POSE, ds, base_intrin=intr, color_dict=p.color_dict, lookup_divisions=div)
+    pool.run_many([frames[0][0]] * len(pool), [frames[0][1]] * len(pool))
+    for q_ in pool.predictors:
+        q_.evaluations = 0
+    t0 = time.perf_counter()
+    res[0] = poses
+    res[1] = pool.run_many([c for c, _ in frames], [d for _, d in frames])
+    p = pool
+elif os.environ.get('ROPE_PREFETCH', '0') != '0':             # Predictor.run_many: frame i+1 prepared while frame i is on the GPU
     res[0] = poses
     res[1] = p.run_many([c for c, _ in frames], [d for _, d in frames])
 else:
