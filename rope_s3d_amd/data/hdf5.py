@@ -11,12 +11,14 @@ import ctypes as C
 import ctypes.util
 import glob
 import os
+import threading
 
 import numpy as np
 
 _HID = C.c_int64
 _HSZ = C.c_uint64
 _LIB = None
+_LOCK = threading.RLock()          # libhdf5 is only thread-safe when built so: one reader at a time
 
 H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0, 1, 2
 H5T_INTEGER, H5T_FLOAT, H5T_STRING = 0, 1, 3
@@ -189,6 +191,10 @@ class H5Array:
 
     def _read(self, start: int, count: int) -> np.ndarray:
         """Rows [start, start+count) of the leading axis (the whole value of a scalar dataset)."""
+        with _LOCK:
+            return self._read_locked(start, count)
+
+    def _read_locked(self, start: int, count: int) -> np.ndarray:
         h = lib()
         shape = (count,) + self.shape[1:] if self.shape else ()
         if self.shape and (count == 0 or 0 in self.shape):
