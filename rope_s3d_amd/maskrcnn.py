@@ -11,7 +11,7 @@ detection threshold 0.7 (pixellib custom_segmentation.inferConfig defaults).
 
 No trained weights exist offline (models/*.h5 are git-ignored upstream), so by default the
 network is random-initialised: it exercises the dense-contraction path (MIOpen convolutions on the
-matrix cores: bf16 weights, channels-last, batch norms folded) and the adapter into `Predictor._segmentLoad`, but its masks
+matrix cores: bf16 weights, batch norms folded) and the adapter into `Predictor._segmentLoad`, but its masks
 are not comparable with the reference's.  `load_matterport_weights` converts a trained Keras weight file of that
 network (the `.h5` PixelLib / Matterport write, training/models.py:180-324 picks one) into this module's state_dict.
 The dense work is the only part of the prediction path where MFMA is the right tool; everything after
@@ -156,72 +156,115 @@ def _iou_over(a: torch.Tensor, b: torch.Tensor, thr: float) -> torch.Tensor:
     return inter / (area_a[:, None] + area_b[None, :] - inter).clamp_(min=1e-12) > thr
 
 
-def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int, block: int = 2048) -> torch.Tensor:
-    """Greedy non-maximum suppression (tf.image.non_max_suppression): indices kept, best first.
+def _iou_over_b(a: torch.Tensor, b: torch.Tensor, thr: float) -> torch.Tensor:
+    """(B, len(a), len(b)) bool: IoU(a[f, i], b[f, j]) > thr for every frame f."""
+    ih = (torch.min(a[:, :, None, 2], b[:, None, :, 2]) - torch.max(a[:, :, None, 0], b[:, None, :, 0])).clamp_(min=0)
+    iw = (torch.min(a[:, :, None, 3], b[:, None, :, 3]) - torch.max(a[:, :, None, 1], b[:, None, :, 1])).clamp_(min=0)
+    inter = ih.mul_(iw)
+    area_a = (a[..., 2] - a[..., 0]).clamp(min=0) * (a[..., 3] - a[..., 1]).clamp(min=0)
+    area_b = (b[..., 2] - b[..., 0]).clamp(min=0) * (b[..., 3] - b[..., 1]).clamp(min=0)
+    return inter / (area_a[:, :, None] + area_b[:, None, :] - inter).clamp_(min=1e-12) > thr
+
+
+def _nms_batched(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int, block: int = 2048, valid: torch.Tensor = None,
+                 groups: torch.Tensor = None) -> torch.Tensor:
+    """Greedy non-maximum suppression (tf.image.non_max_suppression) of B independent box sets at once:
+    boxes (B, N, 4), scores (B, N) -> keep (B, N) bool over the INPUT order, at most `limit` per set (the best ones).
 
     The greedy rule "box j stays unless an earlier box that stays overlaps it" has exactly one solution; instead of
     sweeping the boxes one by one it is iterated as a whole on the device — keep <- alive and not any(earlier & keep &
     overlap) — until nothing changes (after t rounds at least the first t boxes are final; a dozen rounds settle
-    thousands).  Boxes go through in blocks of `block` by descending score: a block is first thinned by the boxes
-    already kept, then settled internally, and the walk stops as soon as `limit` boxes are kept — most of the
-    pairwise overlaps of a 6000-proposal frame are never computed, and nothing runs per box on the host."""
+    thousands).  Boxes go through in blocks of `block` by descending score: a block is first thinned by the boxes kept
+    in earlier blocks, then settled internally, and the walk stops as soon as every set holds `limit` boxes — most of
+    the pairwise overlaps of a 6000-proposal frame are never computed, and nothing runs per box or per frame on the host.
+    `valid` (B, N) masks padding; `groups` (B, N) restricts suppression to boxes of the same group (per-class NMS)."""
+    B, N = scores.shape
+    keep_in = torch.zeros((B, N), dtype=torch.bool, device=boxes.device)
+    if N == 0:
+        return keep_in
+    key = scores if valid is None else torch.where(valid, scores, torch.full_like(scores, -float('inf')))
+    order = key.argsort(dim=1, descending=True, stable=True)
+    b = boxes.gather(1, order[..., None].expand(-1, -1, 4)).float()
+    ok = torch.ones((B, N), dtype=torch.bool, device=boxes.device) if valid is None else valid.gather(1, order)
+    g = None if groups is None else groups.gather(1, order)
+    kept = torch.zeros((B, N), dtype=torch.bool, device=boxes.device)          # over the sorted order
+    for start in range(0, N, block):
+        blk = b[:, start:start + block]
+        m = blk.shape[1]
+        alive = ok[:, start:start + m].clone()
+        if start:
+            over = _iou_over_b(b[:, :start], blk, thr) & kept[:, :start, None]
+            if g is not None:
+                over &= g[:, :start, None] == g[:, None, start:start + m]
+            alive &= ~over.any(1)
+        sup = _iou_over_b(blk, blk, thr).triu_(1)                              # [f, i, j]: earlier i suppresses j
+        if g is not None:
+            sup &= g[:, start:start + m, None] == g[:, None, start:start + m]
+        keep = alive
+        for _ in range(0, m, 4):                                               # four rounds between convergence checks: the
+            prev = keep                                                        # fixed point is stable under further rounds,
+            for _ in range(4):                                                 # and every check is a host synchronisation
+                prev, keep = keep, alive & ~(sup & keep[:, :, None]).any(1)
+            if torch.equal(prev, keep):
+                break
+        kept[:, start:start + m] = keep
+        if bool((kept.sum(1) >= limit).all()):
+            break
+    kept &= kept.cumsum(1) <= limit                                            # the first `limit` of every set
+    return keep_in.scatter_(1, order, kept)
+
+
+def _nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: int, block: int = 2048) -> torch.Tensor:
+    """One box set: indices kept, best first."""
     if boxes.numel() == 0:
         return torch.zeros(0, dtype=torch.long, device=boxes.device)
-    order = scores.argsort(descending=True, stable=True)
-    b = boxes[order].float()
-    kept, kept_boxes, n_kept = [], b[:0], 0
-    for start in range(0, len(b), block):
-        blk = b[start:start + block]
-        alive = torch.ones(len(blk), dtype=torch.bool, device=b.device)
-        if n_kept:
-            alive &= ~_iou_over(kept_boxes, blk, thr).any(0)
-        sup = _iou_over(blk, blk, thr).triu_(1)                       # [i, j]: earlier i suppresses j
-        keep = alive
-        for _ in range(len(blk)):
-            new = alive & ~(sup & keep[:, None]).any(0)
-            if torch.equal(new, keep):
-                break
-            keep = new
-        idx = keep.nonzero().squeeze(1)
-        kept.append(idx + start)
-        kept_boxes = torch.cat([kept_boxes, blk[idx]])
-        n_kept += len(idx)
-        if n_kept >= limit:
-            break
-    return order[torch.cat(kept)[:limit]]
+    keep = _nms_batched(boxes[None], scores[None], thr, limit, block)[0]
+    idx = keep.nonzero().squeeze(1)
+    return idx[scores[idx].argsort(descending=True, stable=True)]
 
 
-def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: int) -> torch.Tensor:
+def _pack_levels(feats: List[torch.Tensor]):
+    """P2..P5 as one table of channel rows, one per feature pixel of every frame and level, plus where each level starts."""
+    lv = feats[:4]
+    C = lv[0].shape[1]
+    rows = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, C) for f in lv])
+    dev = rows.device
+    Hs = torch.tensor([f.shape[2] for f in lv], device=dev)
+    Ws = torch.tensor([f.shape[3] for f in lv], device=dev)
+    sizes = [f.shape[0] * f.shape[2] * f.shape[3] for f in lv]
+    offs = torch.tensor([sum(sizes[:k]) for k in range(4)], device=dev)
+    return rows, Hs, Ws, offs
+
+
+def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: int, frame: torch.Tensor = None, packed=None) -> torch.Tensor:
     """PyramidROIAlign: level by box area, then tf.image.crop_and_resize (bilinear, pool x pool samples spanning
-    the box, corners included).  Four gathers per level straight from the (C,H,W) map: no per-ROI feature copies."""
-    h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
-    lvl = (4 + torch.log2((h * w).clamp(min=1e-12).sqrt() / (224.0 / size)).round()).clamp(2, 5).long()
-    C = feats[0].shape[1]
-    out = boxes.new_zeros((len(boxes), C, pool, pool), dtype=feats[0].dtype)
+    the box, corners included) — for all boxes of all levels and frames in one pass: four gathers of whole channel
+    rows from the packed level table (`_pack_levels`), no per-level loop, no per-ROI feature copies.
+    `frame` (K,) names the batch entry every box belongs to (default: entry 0)."""
+    rows, Hs, Ws, offs = packed if packed is not None else _pack_levels(feats)
+    K, C = len(boxes), rows.shape[1]
+    if frame is None:
+        frame = torch.zeros(K, dtype=torch.long, device=boxes.device)
+    b = boxes.float()
+    h, w = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    li = (4 + torch.log2((h * w).clamp(min=1e-12).sqrt() / (224.0 / size)).round()).clamp(2, 5).long() - 2
+    Hf, Wf = Hs[li], Ws[li]                                         # (K,) size of every box's level
+    base = (offs[li] + frame * (Hf * Wf))[:, None, None]
     t = torch.linspace(0, 1, pool, device=boxes.device)
-    for k in range(2, 6):
-        idx = (lvl == k).nonzero().squeeze(1)
-        if idx.numel() == 0:
-            continue
-        f = feats[k - 2][0]                                          # (C, Hf, Wf)
-        Hf, Wf = f.shape[1], f.shape[2]
-        b = boxes[idx].float()
-        ys = (b[:, 0:1] + t[None, :] * (b[:, 2:3] - b[:, 0:1])) * (Hf - 1)     # (K, P) in feature pixels
-        xs = (b[:, 1:2] + t[None, :] * (b[:, 3:4] - b[:, 1:2])) * (Wf - 1)
-        y0, x0 = ys.floor(), xs.floor()
-        wy, wx = (ys - y0).to(f.dtype), (xs - x0).to(f.dtype)
-        inside_y = ((ys >= 0) & (ys <= Hf - 1)).to(f.dtype)          # crop_and_resize extrapolates with 0 outside the map
-        inside_x = ((xs >= 0) & (xs <= Wf - 1)).to(f.dtype)
-        y0c, y1c = y0.long().clamp(0, Hf - 1), (y0.long() + 1).clamp(0, Hf - 1)
-        x0c, x1c = x0.long().clamp(0, Wf - 1), (x0.long() + 1).clamp(0, Wf - 1)
+    ys = (b[:, 0:1] + t[None, :] * (b[:, 2:3] - b[:, 0:1])) * (Hf - 1)[:, None]      # (K, P) in feature pixels
+    xs = (b[:, 1:2] + t[None, :] * (b[:, 3:4] - b[:, 1:2])) * (Wf - 1)[:, None]
+    y0, x0 = ys.floor(), xs.floor()
+    wy, wx = (ys - y0).to(rows.dtype)[:, :, None, None], (xs - x0).to(rows.dtype)[:, None, :, None]
+    inside = (((ys >= 0) & (ys <= (Hf - 1)[:, None]))[:, :, None] & ((xs >= 0) & (xs <= (Wf - 1)[:, None]))[:, None, :])   # crop_and_resize: 0 outside the map
+    hm, wm = (Hf - 1)[:, None], (Wf - 1)[:, None]
+    y0c, y1c = y0.long().clamp(min=0).minimum(hm), (y0.long() + 1).clamp(min=0).minimum(hm)
+    x0c, x1c = x0.long().clamp(min=0).minimum(wm), (x0.long() + 1).clamp(min=0).minimum(wm)
+    Wk = Wf[:, None, None]
 
-        def g(yi, xi):                                               # -> (C, K, P, P)
-            return f[:, yi[:, :, None].expand(-1, -1, pool), xi[:, None, :].expand(-1, pool, -1)]
-        wy_, wx_ = wy[None, :, :, None], wx[None, :, None, :]
-        val = (g(y0c, x0c) * (1 - wy_) + g(y1c, x0c) * wy_) * (1 - wx_) + (g(y0c, x1c) * (1 - wy_) + g(y1c, x1c) * wy_) * wx_
-        val = val * inside_y[None, :, :, None] * inside_x[None, :, None, :]
-        out[idx] = val.permute(1, 0, 2, 3)
-    return out
+    def g(yi, xi):                                                  # -> (K, P, P, C): whole channel rows by flat pixel index
+        return rows.index_select(0, (base + yi[:, :, None] * Wk + xi[:, None, :]).reshape(-1)).view(K, pool, pool, C)
+    val = (g(y0c, x0c) * (1 - wy) + g(y1c, x0c) * wy) * (1 - wx) + (g(y0c, x1c) * (1 - wy) + g(y1c, x1c) * wy) * wx
+    return (val * inside[..., None].to(rows.dtype)).permute(0, 3, 1, 2)
 
 
 def _fold_batchnorm(module: nn.Module) -> nn.Module:
@@ -284,25 +327,69 @@ class MaskRCNN(nn.Module):
         x = x - torch.tensor(MEAN_PIXEL, device=dev).view(1, 3, 1, 1)
         x = F.pad(x, (left, self.size - nw - left, top, self.size - nh - top))
         wdt = next(self.parameters()).dtype                              # bf16 on the GPU (cast once), f32 on CPU
-        feats_all = self.fpn(self.backbone(x.to(wdt).contiguous(memory_format=torch.channels_last)))
-        rpn_all = [self.rpn(p) for p in feats_all]
-        out = []
-        for b in range(len(images)):
-            feats = [f[b:b + 1] for f in feats_all]
-            probs = torch.cat([r[0][b:b + 1] for r in rpn_all], 1)[0]
-            deltas = torch.cat([r[1][b:b + 1] for r in rpn_all], 1)[0]
-            out.append(self._detect_one(feats, probs, deltas, H, W, scale, top, left, nh, nw))
-        return out
+        feats_all, probs, deltas = self._trunk_replayed(x.to(wdt).contiguous())
+        return self._detect(feats_all, probs, deltas, H, W, scale, top, left, nh, nw)
 
-    def _detect_one(self, feats, probs, deltas, H, W, scale, top, left, nh, nw):
-        dev = probs.device
+    def _trunk(self, x):
+        """Backbone, FPN and the RPN heads: the static-shape, dense part -> (P2..P6, objectness (B, anchors), deltas (B, anchors, 4))."""
+        # the ResNet trunk runs in NCHW, the 256-channel FPN / RPN convolutions in channels-last (each the faster layout
+        # for its shapes on gfx950) — and channels-last maps make _pack_levels a view
+        cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if x.is_cuda else (lambda t: t)
+        feats = self.fpn([cl(c) for c in self.backbone(x)])
+        rpn = [self.rpn(p) for p in feats]
+        return feats, torch.cat([r[0] for r in rpn], 1), torch.cat([r[1] for r in rpn], 1)
+
+    def _trunk_replayed(self, x):
+        """On the GPU the trunk is ~400 small launches whose issue time exceeds their run time: it is captured once per
+        input shape into a HIP graph and replayed with one launch (static input and output buffers; the outputs are
+        consumed by _detect before the next replay, on the same stream).  ROPE_SEG_GRAPH=0, or a failed capture, runs
+        it eagerly — the same operations either way."""
+        import os
+        if not x.is_cuda or os.environ.get('ROPE_SEG_GRAPH', '1') == '0' or getattr(self, '_graph_broken', False):
+            return self._trunk(x)
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        key = (tuple(x.shape), x.dtype)
+        if key not in self._graphs:
+            try:
+                static_x = x.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):                                   # MIOpen settles its kernel choice outside the capture
+                        self._trunk(static_x)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._trunk(static_x)
+                self._graphs[key] = (graph, static_x, static_out)
+            except Exception as e:                                       # noqa: BLE001 — capture support varies; eager is the same math
+                import warnings
+                warnings.warn(f"HIP graph capture of the Mask R-CNN trunk failed ({e}); running it eagerly")
+                self._graph_broken = True
+                torch.cuda.synchronize()
+                return self._trunk(x)
+        graph, static_x, static_out = self._graphs[key]
+        static_x.copy_(x)
+        graph.replay()
+        return static_out
+
+    def _detect(self, feats, probs, deltas, H, W, scale, top, left, nh, nw):
+        """Proposal layer, pyramid RoIAlign, classifier head, detection layer, mask head and un-moulding for all B frames
+        of the batch together: every step works on the concatenation of the frames' boxes with a frame index beside
+        them; only the final split of the masks is per frame."""
+        dev, B = probs.device, probs.shape[0]
         window = torch.tensor([top, left, top + nh, left + nw], device=dev, dtype=torch.float32)
         anchors = _pyramid_anchors(self.size, dev)
-        k = min(PRE_NMS_LIMIT, len(probs))
-        top_idx = probs.topk(k).indices
-        boxes = _apply_deltas(anchors[top_idx], deltas[top_idx] * torch.tensor(RPN_BBOX_STD_DEV, device=dev)).clamp(0, 1)
-        rois = boxes[_nms(boxes, probs[top_idx], RPN_NMS_THRESHOLD, POST_NMS_ROIS)]
-        h = self.head(_roi_align(feats, rois, POOL_SIZE, self.size)).flatten(1)
+        k = min(PRE_NMS_LIMIT, probs.shape[1])
+        top_p, top_idx = probs.topk(k, dim=1)                               # (B, k)
+        d = deltas.gather(1, top_idx[..., None].expand(-1, -1, 4)) * torch.tensor(RPN_BBOX_STD_DEV, device=dev)
+        boxes = _apply_deltas(anchors[top_idx].reshape(-1, 4), d.reshape(-1, 4)).clamp(0, 1).view(B, k, 4)
+        keep = _nms_batched(boxes, top_p, RPN_NMS_THRESHOLD, POST_NMS_ROIS)
+        frame, pos = keep.nonzero(as_tuple=True)                            # proposals of all frames, frame-major, by anchor rank
+        rois = boxes[frame, pos]
+        packed = _pack_levels(feats)
+        h = self.head(_roi_align(feats, rois, POOL_SIZE, self.size, frame, packed)).flatten(1)
         cls_prob = self.cls(h).float().softmax(-1)
         box_delta = self.box(h).float().view(-1, self.num_classes, 4)
         cls_id = cls_prob.argmax(1)
@@ -312,18 +399,31 @@ class MaskRCNN(nn.Module):
         refined = _apply_deltas(rois, d)
         refined = torch.stack([refined[:, 0].clamp(nwin[0], nwin[2]), refined[:, 1].clamp(nwin[1], nwin[3]),
                                refined[:, 2].clamp(nwin[0], nwin[2]), refined[:, 3].clamp(nwin[1], nwin[3])], 1)
-        keep = ((cls_id > 0) & (score >= self.min_conf)).nonzero().squeeze(1)
-        final = []
-        for c in cls_id[keep].unique():                                  # per-class NMS (refine_detections_graph)
-            ix = keep[cls_id[keep] == c]
-            final.append(ix[_nms(refined[ix], score[ix], DETECTION_NMS_THRESHOLD, DETECTION_MAX_INSTANCES)])
-        if not final:
-            return (torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros((H, W, 0), dtype=torch.bool))
-        keep = torch.cat(final)
-        keep = keep[score[keep].argsort(descending=True)[:DETECTION_MAX_INSTANCES]]
-        det_boxes, det_cls, det_score = refined[keep], cls_id[keep], score[keep]
-        m = self.mask(_roi_align(feats, det_boxes, MASK_POOL_SIZE, self.size)).float().sigmoid()
-        m = m[torch.arange(len(keep), device=dev), det_cls]              # (K, 28, 28) of each detection's class
+        cand = ((cls_id > 0) & (score >= self.min_conf)).nonzero().squeeze(1)
+        empty = (torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros((H, W, 0), dtype=torch.bool))
+        if cand.numel() == 0:
+            return [empty] * B
+        # per-class NMS of every frame in one pass (refine_detections_graph): suppression only inside (frame, class) groups
+        grp = frame[cand] * self.num_classes + cls_id[cand]
+        kept = _nms_batched(refined[cand][None], score[cand][None], DETECTION_NMS_THRESHOLD, len(cand), groups=grp[None])[0]
+        # at most DETECTION_MAX_INSTANCES per class, then per frame, by score
+        sel = cand[kept]
+        sel = sel[score[sel].argsort(descending=True, stable=True)]
+
+        def first_n(keys, n):                                               # keep the first n (in the current, score order) of every key
+            o = keys.argsort(stable=True)
+            ks = keys[o]
+            start = torch.cat([ks.new_zeros(1, dtype=torch.bool) | True, ks[1:] != ks[:-1]])
+            rank = torch.arange(len(ks), device=dev) - torch.cummax(torch.where(start, torch.arange(len(ks), device=dev), 0), 0).values
+            ok = torch.zeros(len(ks), dtype=torch.bool, device=dev)
+            ok[o] = rank < n
+            return ok
+        sel = sel[first_n(frame[sel] * self.num_classes + cls_id[sel], DETECTION_MAX_INSTANCES)]
+        sel = sel[first_n(frame[sel], DETECTION_MAX_INSTANCES)]
+        sel = sel[frame[sel].argsort(stable=True)]                          # frame-major, best first inside a frame
+        det_boxes, det_cls, det_score, det_frame = refined[sel], cls_id[sel], score[sel], frame[sel]
+        m = self.mask(_roi_align(feats, det_boxes, MASK_POOL_SIZE, self.size, det_frame, packed)).float().sigmoid()
+        m = m[torch.arange(len(sel), device=dev), det_cls]                  # (K, 28, 28) of each detection's class
         # un-mould: boxes back to original image pixels, masks resized into their box (utils.unmold_mask)
         px = det_boxes * (self.size - 1) + torch.tensor([0, 0, 1, 1], device=dev)
         px = ((px - torch.tensor([top, left, top, left], device=dev)) / scale).round().long()
@@ -340,8 +440,20 @@ class MaskRCNN(nn.Module):
         grid = torch.stack([gx.expand(-1, H, W), gy.expand(-1, H, W)], -1)
         val = F.grid_sample(m[:, None], grid, mode='bilinear', padding_mode='border', align_corners=False)[:, 0]
         inside = (Y > y1[:, None, None]) & (Y < y2[:, None, None]) & (X > x1[:, None, None]) & (X < x2[:, None, None])
-        masks = ((val >= 0.5) & inside).permute(1, 2, 0).contiguous()
-        return det_cls.cpu(), det_score.cpu(), masks.cpu()
+        masks = (val >= 0.5) & inside                                       # (K, H, W)
+        if dev.type == 'cuda':                                              # one transfer for the whole batch, through pinned memory
+            host = torch.empty(masks.shape, dtype=torch.bool, pin_memory=True)
+            host.copy_(masks, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            masks = host
+        else:
+            masks = masks.cpu()
+        det_cls, det_score, counts = det_cls.cpu(), det_score.cpu(), torch.bincount(det_frame, minlength=B).cpu().tolist()
+        out, at = [], 0
+        for n in counts:
+            out.append((det_cls[at:at + n], det_score[at:at + n], masks[at:at + n].permute(1, 2, 0).contiguous()) if n else empty)
+            at += n
+        return out
 
 
 def matterport_layer_map(num_classes: int = 7) -> dict:
@@ -447,7 +559,9 @@ class MaskRCNNSegmenter:
             self.net.load_state_dict(state_dict)
         self.net = _fold_batchnorm(self.net.eval()).to(self.device)
         if self.device.type == 'cuda':                                   # weights to bf16 once: MFMA path of MIOpen / hipBLASLt
-            self.net = self.net.to(torch.bfloat16).to(memory_format=torch.channels_last)
+            self.net = self.net.to(torch.bfloat16)
+            for part in (self.net.fpn, self.net.rpn):                      # see detect_batch for the layouts
+                part.to(memory_format=torch.channels_last)
 
     def __call__(self, color_bgr: np.ndarray) -> dict:
         return self.batch([color_bgr])[0]

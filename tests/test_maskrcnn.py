@@ -211,3 +211,30 @@ def test_predictor_loads_the_trained_model_of_its_dataset(tmp_path):
     color, depth = sp.renderer.render()
     out = p.run(color, depth.astype(np.float64))
     assert out.shape == (6,) and np.isfinite(out).all()
+
+
+def test_batched_nms_equals_set_by_set():
+    """_nms_batched: B box sets at once, padding masked out, per-class groups — against _nms run set by set / group by
+    group (which test_device_nms_equals_the_one_by_one_sweep ties to the literal greedy sweep)."""
+    from rope_s3d_amd.maskrcnn import _nms_batched
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 700
+    c = torch.rand(B, N, 2, generator=g)
+    wh = torch.rand(B, N, 2, generator=g) * 0.2 + 0.02
+    boxes = torch.cat([c - wh / 2, c + wh / 2], -1)
+    scores = torch.rand(B, N, generator=g)
+    valid = torch.ones(B, N, dtype=torch.bool)
+    valid[1, 400:] = False                                                  # a shorter set, padded
+    keep = _nms_batched(boxes, scores, 0.3, 50, block=256, valid=valid)
+    for f in range(B):
+        n = int(valid[f].sum())
+        want = _nms(boxes[f, :n], scores[f, :n], 0.3, 50, block=256)
+        assert sorted(keep[f].nonzero().squeeze(1).tolist()) == sorted(want.tolist()) and not keep[f, n:].any()
+    groups = torch.randint(0, 4, (1, N), generator=g)
+    keep = _nms_batched(boxes[:1], scores[:1], 0.3, N, block=128, groups=groups)[0]
+    want = []
+    for k in range(4):
+        ix = (groups[0] == k).nonzero().squeeze(1)
+        want += ix[_nms(boxes[0, ix], scores[0, ix], 0.3, N)].tolist()
+    assert sorted(keep.nonzero().squeeze(1).tolist()) == sorted(want)
+    assert _nms_batched(boxes[:, :0], scores[:, :0], 0.3, 5).shape == (B, 0)
