@@ -87,6 +87,11 @@ int rope_set_camera(rope_ctx *ctx, const double *PV, int W, int H, double znear,
  *   link_flags 8 bytes: bit0 link present in the target, bit1 ">5 % of mask has depth" (predict.py:495) */
 int rope_set_target(rope_ctx *ctx, const uint64_t *tq, const float *t32, const uint8_t *link_flags);
 
+/* Host only (no context): the packing rope_set_target expects.  depth n float64 metres (NaN, inf and values <= 0 count
+ * as "no depth"), mask_bits n bytes (bit l = link l's mask) or NULL -> out n uint64: Q32 depth, round half even,
+ * clipped to 2^39-1, mask bits at 40..47. */
+int rope_pack_target(const double *depth, const uint8_t *mask_bits, int64_t n, uint64_t *out);
+
 /* Candidate joint vectors (C x 6 doubles) into HBM; they stay resident until replaced. */
 int rope_candidates_upload(rope_ctx *ctx, const double *cand, int C);
 

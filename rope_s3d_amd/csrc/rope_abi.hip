@@ -352,6 +352,21 @@ extern "C" int rope_set_target(rope_ctx *c, const uint64_t *tq, const float *t32
     return ROPE_OK;
 }
 
+// Host only: float64 metres + link-mask bits -> the packed plane of rope_set_target.  nearbyint under the default
+// rounding mode is numpy's rint (round half to even).
+extern "C" int rope_pack_target(const double *depth, const uint8_t *mask_bits, int64_t n, uint64_t *out)
+{
+    if (!depth || !out || n < 0) return ROPE_E_ARG;
+    const double Q32 = 4294967296.0, top = 549755813887.0;          // 2^32, 2^39 - 1
+    for (int64_t i = 0; i < n; i++) {
+        const double d = depth[i];
+        double q = (std::isfinite(d) && d > 0.0) ? std::nearbyint(d * Q32) : 0.0;
+        q = q < top ? q : top;
+        out[i] = (uint64_t)q | (mask_bits ? (uint64_t)mask_bits[i] << 40 : 0);
+    }
+    return ROPE_OK;
+}
+
 static int ensure_capacity(rope_ctx *c, int C)
 {
     if (C <= c->cap) return ROPE_OK;

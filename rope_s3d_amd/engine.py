@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip',
-    'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh')
+    'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP = 0, 1, 2, 3
@@ -88,6 +88,7 @@ def load_library(path: str = None):
     lib.rope_predict.argtypes = [vp, C.POINTER(PredictArgs), vp, vp, C.POINTER(C.c_int64)]
     lib.rope_set_robot_mesh.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     lib.rope_partition_mesh.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
+    lib.rope_pack_target.argtypes = [vp, vp, C.c_int64, vp]
     lib.rope_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
     _lib = lib
@@ -105,6 +106,12 @@ def pack_target(depth: np.ndarray, mask_bits: np.ndarray = None) -> np.ndarray:
     negatives count as "no depth" = 0); bits 40..47: bit l set where link l's mask is true.
     """
     d = np.asarray(depth, np.float64)
+    if _lib is not None or os.path.exists(os.environ.get('ROPE_HIP_LIB', LIB_PATH)):       # one pass in the library (host code, no GPU)
+        d = np.ascontiguousarray(d)
+        bits = None if mask_bits is None else np.ascontiguousarray(mask_bits, np.uint8)
+        out = np.empty(d.shape, np.uint64)
+        if load_library().rope_pack_target(_p(d), _p(bits), d.size, _p(out)) == 0:
+            return out
     q = np.rint(np.where(np.isfinite(d) & (d > 0), d, 0.0) * Q32)
     q = np.minimum(q, float(TQ_MAX)).astype(np.uint64)
     if mask_bits is not None:

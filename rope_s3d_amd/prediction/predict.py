@@ -275,7 +275,7 @@ class Predictor:
     def _loadSynthetic(self, target_color, target_depth):
         """Synthetic path: link masks are read off channel 0 of the colour render (predict.py:445-469)."""
         target_color = self._downsample(target_color, self.ds_factor)
-        blue = target_color[..., 0]
+        blue = np.ascontiguousarray(target_color[..., 0])          # contiguous: the comparisons below run over it a dozen times
         hit = np.zeros(target_depth.shape, bool)            # the reference sums the comparisons and casts to bool (predict.py:449-454)
         for k in self.color_dict:
             if k in self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED]:
