@@ -577,12 +577,17 @@ class BatchAheadSegmenter:
     """Segments the frames a caller is about to predict in batches, then hands the results out one by one.
 
     `announce(frames)` takes the down-sampled colour images of the coming frames (any number) and runs them through
-    `segmenter.batch` in groups of `batch`; `__call__(frame)` returns the stored result of that frame (matched by
-    content), or segments it on the spot if it was not announced.  Single-threaded: the point is the batch efficiency
-    of the convolutions, not overlap."""
+    `segmenter.batch` in groups of `batch` on a background thread; `__call__(frame)` returns the result of that frame
+    (matched by content) as soon as its group is through — the network works ahead of the stage machine, which spends
+    most of its time inside the library with the interpreter lock released — or segments the frame on the spot if it
+    was not announced.  `background=False` does the batches inside announce()."""
 
-    def __init__(self, segmenter: MaskRCNNSegmenter, batch: int = 8):
-        self._seg, self._batch, self._store = segmenter, int(batch), {}
+    def __init__(self, segmenter: MaskRCNNSegmenter, batch: int = 8, background: bool = True):
+        import threading
+        self._seg, self._batch, self._background = segmenter, int(batch), background
+        self._store, self._pending, self._error = {}, {}, None
+        self._cv = threading.Condition()
+        self._seg_lock = threading.Lock()                 # one user of the network (and of its graph buffers) at a time
 
     @staticmethod
     def _key(color: np.ndarray):
@@ -590,12 +595,46 @@ class BatchAheadSegmenter:
         return (a.shape, a[::5, ::5].tobytes())
 
     def announce(self, frames):
+        import threading
         frames = [np.asarray(f) for f in frames]
-        for i in range(0, len(frames), self._batch):
-            group = frames[i:i + self._batch]
-            for f, r in zip(group, self._seg.batch(group)):
-                self._store[self._key(f)] = r
+        keys = [self._key(f) for f in frames]
+        with self._cv:
+            for k in keys:
+                self._pending[k] = self._pending.get(k, 0) + 1
+        if self._background:
+            threading.Thread(target=self._work, args=(frames, keys), daemon=True).start()
+        else:
+            self._work(frames, keys)
+
+    def _work(self, frames, keys):
+        try:
+            for i in range(0, len(frames), self._batch):
+                with self._seg_lock:
+                    results = self._seg.batch(frames[i:i + self._batch])
+                with self._cv:
+                    for k, r in zip(keys[i:i + self._batch], results):
+                        self._store.setdefault(k, []).append(r)
+                        self._pending[k] -= 1
+                    self._cv.notify_all()
+        except BaseException as e:                        # noqa: BLE001 — handed to the consumer, which re-raises it
+            with self._cv:
+                self._error = e
+                self._cv.notify_all()
 
     def __call__(self, color: np.ndarray) -> dict:
-        r = self._store.pop(self._key(color), None)
-        return r if r is not None else self._seg(color)
+        k = self._key(color)
+        with self._cv:
+            while True:
+                if self._error is not None:
+                    raise self._error
+                ready = self._store.get(k)
+                if ready:
+                    r = ready.pop(0)
+                    if not ready:
+                        del self._store[k]
+                    return r
+                if self._pending.get(k, 0) <= 0:
+                    break                                 # never announced (or already handed out): segment it now
+                self._cv.wait()
+        with self._seg_lock:
+            return self._seg(color)
