@@ -437,7 +437,7 @@ def test_predict_dataset_reads_the_reference_hdf5_form(tmp_path, monkeypatch):
     monkeypatch.setenv('WORLD_SIZE', '1')
     pd = importlib.import_module('predict_dataset')
     want = pd.run(argparse.Namespace(dataset=d, angs='SLU', ds_factor=4))
-    got = pd.run(argparse.Namespace(dataset=os.path.dirname(h5), angs='SLU', ds_factor=4))
+    got = pd.run(argparse.Namespace(dataset=os.path.dirname(h5), angs='SLU', ds_factor=4, predictors=2))      # and two Predictors on the GPU
     assert np.array_equal(got, want)
     assert np.array_equal(np.load(tmp_path / 'predictions_synth3h.npy'), want)
 
