@@ -1,11 +1,12 @@
 #!/bin/bash
 # MFMA utilisation of the segmentation stage (counters in their own run), summarised on the box.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+SCRIPT=${1:-bench_seg.py}          # bench_seg.py: frame by frame; bench_seg_batch.py: batches of 8 (run with ROPE_SEG_GRAPH=0 for per-kernel counters)
 OUT=/tmp/prof_seg
 rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 $ROOT/tools/bench_seg.py 5 > $OUT/pmc.log 2>&1 || { tail -5 $OUT/pmc.log; exit 1; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/bench_seg.py 5 > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 $ROOT/tools/$SCRIPT 5 > $OUT/pmc.log 2>&1 || { tail -5 $OUT/pmc.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/$SCRIPT 5 > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 python3 - <<'PY' > $ROOT/gpurun_out/seg_profile.txt
 import csv, glob, collections
 agg = collections.defaultdict(float)
