@@ -453,3 +453,15 @@ def test_native_and_python_partitioners_agree_in_kind():
     assert lib.rope_partition_mesh(p(V), len(V), p(F), len(F), 129, 64, p(order), p(first)) == -1
     assert lib.rope_partition_mesh(p(V), len(V), p(F), len(F), 128, 65, p(order), p(first)) == -1
     assert lib.rope_partition_mesh(p(V), len(V), p(F), 0, 128, 64, p(order), p(first)) == -1
+
+
+def test_reference_import_lines_resolve():
+    """The import lines of the reference's callers for this path, verbatim (predict_dataset.py:13, predict_live.py:1-4,
+    synth.py:13, camera pose scripts): they must resolve against this repository."""
+    from robotpose import Dataset, Grapher, Predictor                                            # noqa: F401
+    from robotpose import Intrinsics, JSONCoupling, LiveCamera                                   # noqa: F401
+    from robotpose.prediction.analysis import JointDistance                                      # noqa: F401
+    from robotpose.prediction.camera_pose_prediction import CameraPredictor, ModellessCameraPredictor   # noqa: F401
+    from robotpose.utils import color_array, str_to_arr                                          # noqa: F401
+    import rope_s3d_amd
+    assert Predictor is rope_s3d_amd.Predictor and Dataset is rope_s3d_amd.Dataset
