@@ -92,6 +92,12 @@ int rope_set_target(rope_ctx *ctx, const uint64_t *tq, const float *t32, const u
  * clipped to 2^39-1, mask bits at 40..47. */
 int rope_pack_target(const double *depth, const uint8_t *mask_bits, int64_t n, uint64_t *out);
 
+/* Host only (no context): cv2.resize(img, (W/f, H/f)) with INTER_LINEAR for an even integer factor f — the frame
+ * down-sampling of Predictor._downsample (predict.py:378-381); four taps per output sample, OpenCV's fixed-point
+ * rounding for uint8.  kind 0 uint8, 1 float32, 2 float64; `channels` interleaved; rows `row_stride` bytes apart;
+ * dst is dense (H/f x W/f x channels). */
+int rope_downsample_even(const void *src, int H, int W, int channels, int64_t row_stride, int f, int kind, void *dst);
+
 /* Candidate joint vectors (C x 6 doubles) into HBM; they stay resident until replaced. */
 int rope_candidates_upload(rope_ctx *ctx, const double *cand, int C);
 

@@ -367,6 +367,42 @@ extern "C" int rope_pack_target(const double *depth, const uint8_t *mask_bits, i
     return ROPE_OK;
 }
 
+// Host only: cv2.resize(img, (W/f, H/f)) with INTER_LINEAR for an EVEN integer factor f (Predictor._downsample,
+// predict.py:378-381).  The source coordinate of every output sample falls exactly between the two central taps of its
+// f x f block (f/2-1 and f/2), both with weight 1/2, so the general interpolation collapses to four taps per sample:
+//   kind 0  uint8 : OpenCV's fixed-point path — horizontal pass with 11-bit weights, >> 4, vertical pass >> 16, + 2 >> 2
+//   kind 1  float32, kind 2 float64 : (a*w + b*w) per row, then (top*w + bottom*w), w = 0.5 in the image's own type
+// `channels` interleaved values per pixel; rows are `row_stride` BYTES apart (a strided view is fine).
+extern "C" int rope_downsample_even(const void *src, int H, int W, int channels, int64_t row_stride, int f, int kind, void *dst)
+{
+    if (!src || !dst || H < 1 || W < 1 || channels < 1 || f < 2 || (f & 1) || H % f || W % f || kind < 0 || kind > 2) return ROPE_E_ARG;
+    const int oh = H / f, ow = W / f, a = f / 2 - 1, b = f / 2;
+    const char *base = (const char *)src;
+    for (int y = 0; y < oh; y++) {
+        const char *r0 = base + (int64_t)(y * f + a) * row_stride, *r1 = base + (int64_t)(y * f + b) * row_stride;
+        for (int x = 0; x < ow; x++)
+            for (int ch = 0; ch < channels; ch++) {
+                const size_t ia = (size_t)(x * f + a) * channels + ch, ib = (size_t)(x * f + b) * channels + ch;
+                const size_t o = ((size_t)y * ow + x) * channels + ch;
+                if (kind == 0) {
+                    const uint8_t *p0 = (const uint8_t *)r0, *p1 = (const uint8_t *)r1;
+                    const int64_t t = ((int64_t)p0[ia] * 1024 + (int64_t)p0[ib] * 1024) >> 4, u = ((int64_t)p1[ia] * 1024 + (int64_t)p1[ib] * 1024) >> 4;
+                    int64_t v = (((1024 * t) >> 16) + ((1024 * u) >> 16) + 2) >> 2;
+                    ((uint8_t *)dst)[o] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                } else if (kind == 1) {
+                    const float *p0 = (const float *)r0, *p1 = (const float *)r1;
+                    const float top = p0[ia] * 0.5f + p0[ib] * 0.5f, bot = p1[ia] * 0.5f + p1[ib] * 0.5f;
+                    ((float *)dst)[o] = top * 0.5f + bot * 0.5f;
+                } else {
+                    const double *p0 = (const double *)r0, *p1 = (const double *)r1;
+                    const double top = p0[ia] * 0.5 + p0[ib] * 0.5, bot = p1[ia] * 0.5 + p1[ib] * 0.5;
+                    ((double *)dst)[o] = top * 0.5 + bot * 0.5;
+                }
+            }
+    }
+    return ROPE_OK;
+}
+
 static int ensure_capacity(rope_ctx *c, int C)
 {
     if (C <= c->cap) return ROPE_OK;

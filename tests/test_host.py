@@ -465,3 +465,38 @@ def test_reference_import_lines_resolve():
     from robotpose.utils import color_array, str_to_arr                                          # noqa: F401
     import rope_s3d_amd
     assert Predictor is rope_s3d_amd.Predictor and Dataset is rope_s3d_amd.Dataset
+
+
+def test_native_downsample_equals_the_numpy_path():
+    """rope_downsample_even (the library's one-pass even-factor INTER_LINEAR) against imgproc's numpy gathers, which
+    test_resize_linear_is_cv2_inter_linear ties to the general interpolation: uint8 / float32 / float64, 1 and 3 channels."""
+    from rope_s3d_amd import imgproc
+    rng = np.random.default_rng(8)
+    seen = []
+    orig = imgproc._downsample_native
+
+    def spy(img, f):
+        out = orig(img, f)
+        seen.append(out is not None)
+        return out
+    for dt in (np.uint8, np.float32, np.float64):
+        for shape, f in (((72, 128, 3), 8), ((72, 128), 8), ((48, 64), 2), ((36, 60, 3), 6)):
+            img = rng.uniform(0, 255, shape).astype(dt) if dt == np.uint8 else (rng.uniform(0, 3, shape) * (rng.uniform(size=shape) > .3)).astype(dt)
+            H, W = shape[:2]
+            imgproc._downsample_native = spy
+            try:
+                got = imgproc.resize_linear(img, W // f, H // f)
+                imgproc._downsample_native = lambda *a: None
+                want = imgproc.resize_linear(img, W // f, H // f)
+                rev = imgproc.resize_linear(img[:, ::-1], W // f, H // f)            # negative pixel stride: numpy path
+            finally:
+                imgproc._downsample_native = orig
+            assert got.dtype == want.dtype == dt and np.array_equal(got, want)
+            assert np.array_equal(rev, imgproc.resize_linear(np.ascontiguousarray(img[:, ::-1]), W // f, H // f))
+    assert all(seen) and len(seen) == 12                                             # the library did take every one of them
+    import ctypes as C
+    from rope_s3d_amd.engine import load_library
+    x = np.zeros((8, 8), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert load_library().rope_downsample_even(p(x), 8, 8, 1, 8, 3, 0, p(x)) == -1   # odd factor
+    assert load_library().rope_downsample_even(p(x), 8, 8, 1, 8, 16, 0, p(x)) == -1  # does not divide
