@@ -53,6 +53,10 @@ struct rope_ctx {
     // small batches: the finalize kernel writes errors + best straight into mapped pinned host memory (no copy command)
     static constexpr int HOST_ERR_ROWS = 256;
     double *h_err = nullptr, *d_err_host = nullptr;   // host pointer and its device alias
+    // small batches: the candidates stay in mapped host memory and the FK kernel reads them from there — no copy command
+    // in front of the first launch of a latency-bound chain
+    double *h_cand = nullptr, *d_cand_host = nullptr;
+    const double *cand_dev = nullptr;                  // where the resident candidates are: d_cand or d_cand_host
     bool err_on_host = false;
     float *d_mvp = nullptr;
     short4 *d_bounds = nullptr;
@@ -161,6 +165,8 @@ extern "C" int rope_create(rope_ctx **out, int device)
     }
     if (hipHostMalloc((void **)&c->h_err, (rope_ctx::HOST_ERR_ROWS + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_err_host, c->h_err, 0) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_cand, 6 * rope_ctx::HOST_ERR_ROWS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_cand_host, c->h_cand, 0) != hipSuccess ||
         hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&c->d_best_err, sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_PV, 16 * sizeof(double)) != hipSuccess ||
@@ -214,6 +220,7 @@ extern "C" void rope_destroy(rope_ctx *c)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->h_cand) (void)hipHostFree(c->h_cand);
     if (c->h_vstage) (void)hipHostFree(c->h_vstage);
     if (c->h_vsums) (void)hipHostFree(c->h_vsums);
     if (c->h_copy) (void)hipHostFree(c->h_copy);
@@ -440,8 +447,14 @@ static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
     int rc = ensure_capacity(c, C);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // the staging buffer may still feed an earlier copy
-    std::memcpy(c->h_stage, cand, 6 * (size_t)C * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->d_cand, c->h_stage, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (C <= rope_ctx::HOST_ERR_ROWS) {            // nothing is in flight (synchronised above): the kernels of the next pass read it in place
+        std::memcpy(c->h_cand, cand, 6 * (size_t)C * sizeof(double));
+        c->cand_dev = c->d_cand_host;
+    } else {
+        std::memcpy(c->h_stage, cand, 6 * (size_t)C * sizeof(double));
+        HIP_TRY(c, hipMemcpyAsync(c->d_cand, c->h_stage, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->cand_dev = c->d_cand;
+    }
     // group candidates whose first two joint angles are bit-identical: their base_link, link_1_s and
     // link_2_l transforms are the same bits, so those links are rasterised once per group (a "layer")
     c->n_layers = C;                               // "no sharing" unless the grouping below finds some
@@ -572,7 +585,7 @@ static RasterArgs base_args(rope_ctx *c, int n_render)
 // forward kinematics + link matrices + screen boxes + tile masks (+ cleared sums) of the resident candidates
 static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const FrameParams &fp, bool views)
 {
-    const double *PV = views ? c->dv_PV : c->d_PV, *cand = views ? c->dv_cand : c->d_cand;
+    const double *PV = views ? c->dv_PV : c->d_PV, *cand = views ? c->dv_cand : c->cand_dev;
     const int32_t *view_of = views ? c->dv_view_of : nullptr;
     if (c->C <= 256) {                              // one fused launch, one workgroup per candidate
         HIP_TRY(c, launch_fk_bounds(c->stream, cand, c->C, fp, c->rp, n_render, n_shared, c->d_joint_fixed, c->d_joint_axes, PV,
