@@ -500,3 +500,25 @@ def test_native_downsample_equals_the_numpy_path():
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     assert load_library().rope_downsample_even(p(x), 8, 8, 1, 8, 3, 0, p(x)) == -1   # odd factor
     assert load_library().rope_downsample_even(p(x), 8, 8, 1, 8, 16, 0, p(x)) == -1  # does not divide
+
+
+def test_target_packing_native_numpy_and_oracle_agree():
+    """engine.pack_target (rope_pack_target in the library), its numpy form and the oracle's packer: Q32 round-half-even,
+    NaN / inf / non-positive depth = "no depth", clipping at 2^39-1, link-mask bits at 40..47."""
+    from oracle import oracle as orc
+    from rope_s3d_amd import engine as eng
+    rng = np.random.default_rng(2)
+    d = rng.uniform(-0.5, 3, (37, 53))
+    d[0, :6] = [np.nan, np.inf, -np.inf, 0.0, -0.0, 200.0]
+    d[1, :5] = [0.5 / 2 ** 32, 1.5 / 2 ** 32, 2.5 / 2 ** 32, 127.99999999999, (2 ** 39 - 1) / 2 ** 32]
+    bits = rng.integers(0, 64, d.shape).astype(np.uint8)
+    want = orc.pack_target(d, bits.astype(np.uint64))
+    got = eng.pack_target(d, bits)
+    assert got.dtype == np.uint64 and np.array_equal(got, want)
+    assert np.array_equal(eng.pack_target(d), orc.pack_target(d, None))
+    assert np.array_equal(eng.pack_target(d.astype(np.float32)), orc.pack_target(d.astype(np.float32).astype(np.float64), None))
+    assert np.array_equal(eng.pack_target(np.asfortranarray(d), bits), want)                    # any layout in, C order out
+    q = np.rint(np.where(np.isfinite(d) & (d > 0), d, 0.0) * 2.0 ** 32)
+    assert np.array_equal(got & np.uint64((1 << 40) - 1), np.minimum(q, 2.0 ** 39 - 1).astype(np.uint64))
+    assert got[0, 0] == np.uint64(bits[0, 0]) << np.uint64(40) and (got[1, :3] & np.uint64(0xFF)).tolist() == [0, 2, 2]   # halves to even
+    assert int(got[0, 5]) & ((1 << 40) - 1) == 2 ** 39 - 1                                      # 200 m clips
