@@ -108,3 +108,52 @@ def test_argument_checks_without_an_engine(shim):
         args = PredictArgs(arr, 1, 3, p(lim), p(cam), p(inc), None, 0, 0, None)
         assert shim.rope_predict(C.c_void_p(1), C.byref(args), p(out), None, None) == -1
         assert text in shim.shim_last_error()
+
+
+def test_stage_loop_with_nan_errors_follows_the_reference(shim):
+    """A frame without any depth makes every E(a) NaN (mean of an empty set, predict.py:503-507).  The reference's loop then
+    runs on Python's NaN semantics — comparisons false, min() keeping a leading NaN, interp1d's NaN spline — and the
+    library's loop has to land on the same angles."""
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    away = [0, 5.0, 0.75, 0, 0, 0]                       # the default camera moved past the robot: it now looks away from it
+    intr, PV = helpers.camera('640_480_color', ds=8, pose=away, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    depth = np.zeros((intr.height, intr.width), np.float32)
+    ids = np.full(depth.shape, 255, np.uint8)
+    tq, t32, flags, tgt, _, _ = helpers.synthetic_target(depth, ids)
+    blue = np.zeros(depth.shape, np.uint8)
+    grid = helpers.slu_grid(lim, 3)
+    crop = np.array([0, intr.height - 1, 0, intr.width - 1], np.int32)
+    names = rb.link_names
+    with np.errstate(all='ignore'):
+        want, trace, _ = predictor_ref.predict_reference(o, tgt, blue, names, {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}, lim,
+                                                         away, grid, crop, 'SLU')
+    seen_nan = []
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32))
+    def answer(cand, n, n_render, loss, crop_p, err_out, best_idx):
+        rows = np.ctypeslib.as_array(cand, (n, 6)).copy()
+        if loss == orc.LOSS_LOOKUP:
+            err = o.eval(rows, loss, n_render, tq, t32, np.ctypeslib.as_array(crop_p, (4,)), flags, threads=THREADS)
+        else:
+            err = o.eval(rows, loss, n_render, tq, link_flags=flags, threads=THREADS)
+            seen_nan.append(bool(np.isnan(err).all()))
+        if err_out:
+            np.ctypeslib.as_array(err_out, (n,))[:] = err
+        if best_idx:                       # the engine's rule: first smallest, NaN never wins, all NaN -> row 0
+            ok = ~np.isnan(err)
+            best_idx[0] = int(np.flatnonzero(ok)[np.argmin(err[ok])]) if ok.any() else 0
+        return 0
+    shim.shim_set_callback(answer)
+    stages = _stages('SLU')
+    arr = (StageDesc * len(stages))(*stages)
+    limits, cam, inc = np.ascontiguousarray(lim, np.float64), np.asarray(away, np.float64), np.array([.005] * 6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    args = PredictArgs(arr, len(arr), 3, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop))
+    out, got_trace = np.empty(6), np.empty((len(arr), 6))
+    assert shim.rope_predict(C.c_void_p(1), C.byref(args), p(out), p(got_trace), None) == 0, shim.shim_last_error()
+    assert seen_nan and all(seen_nan)
+    for k, (kind, ang) in enumerate(trace):
+        assert np.array_equal(got_trace[k], ang), (k, kind, got_trace[k], ang)
+    assert np.array_equal(out, want)
