@@ -46,11 +46,15 @@ def _stages(do_angles):
             desc(STAGE_DESCENT, 6, 40, 'SLU', stop=0.0075)]          # stages.py:152-168
 
 
-@pytest.mark.parametrize('do_angles,seed,speculate', [('SLU', 7919, 3), ('SLU', 7920, 1), ('SL', 7921, 3)])
-def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculate):
+TILTED = [0.1, -1.6, 0.8, 0.05, 0.08, -0.1]          # non-zero camera angles: SFlip's axis then mixes cam[4] and cam[5] (predict.py:245)
+
+
+@pytest.mark.parametrize('do_angles,seed,speculate,pose', [('SLU', 7919, 3, DEFAULT_CAMERA_POSE), ('SLU', 7920, 1, DEFAULT_CAMERA_POSE),
+                                                           ('SL', 7921, 3, DEFAULT_CAMERA_POSE), ('SLU', 7922, 3, TILTED)])
+def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculate, pose):
     rb = helpers.robot()
     lim = rb.joint_limits
-    intr, PV = helpers.camera('640_480_color', ds=8, as_predictor=True)          # 80x60: the oracle renders ~500 poses per run
+    intr, PV = helpers.camera('640_480_color', ds=8, pose=pose, as_predictor=True)          # 80x60: the oracle renders ~500 poses per run
     o = helpers.make_oracle(rb, intr, PV)
     q_true = np.random.default_rng(seed).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
     depth, ids = o.render(q_true, 6)
@@ -62,7 +66,7 @@ def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculat
     crop = np.array([max(r.min() - 10, 0), min(r.max() + 10, intr.height - 1), max(c.min() - 10, 0), min(c.max() + 10, intr.width - 1)], np.int32)
     names = rb.link_names
     want, trace, n_eval = predictor_ref.predict_reference(o, tgt, blue, names, {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}, lim,
-                                                          DEFAULT_CAMERA_POSE, grid, crop, do_angles)
+                                                          pose, grid, crop, do_angles)
     calls = []
 
     @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32))
@@ -81,7 +85,7 @@ def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculat
     shim.shim_set_callback(answer)
     stages = _stages(do_angles)
     arr = (StageDesc * len(stages))(*stages)
-    limits, cam, inc = np.ascontiguousarray(lim, np.float64), np.asarray(DEFAULT_CAMERA_POSE, np.float64), np.array([.005] * 6)
+    limits, cam, inc = np.ascontiguousarray(lim, np.float64), np.asarray(pose, np.float64), np.array([.005] * 6)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     args = PredictArgs(arr, len(arr), speculate, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop))
     out, got_trace, n = np.empty(6), np.empty((len(arr), 6)), C.c_int64()
