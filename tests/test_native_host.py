@@ -50,7 +50,9 @@ TILTED = [0.1, -1.6, 0.8, 0.05, 0.08, -0.1]          # non-zero camera angles: S
 
 
 @pytest.mark.parametrize('do_angles,seed,speculate,pose', [('SLU', 7919, 3, DEFAULT_CAMERA_POSE), ('SLU', 7920, 1, DEFAULT_CAMERA_POSE),
-                                                           ('SL', 7921, 3, DEFAULT_CAMERA_POSE), ('SLU', 7922, 3, TILTED)])
+                                                           ('SL', 7921, 3, DEFAULT_CAMERA_POSE), ('SLU', 7922, 3, TILTED)]
+                         + [('SLU' if k % 3 else 'SL', 9000 + k, 1 + k % 3, TILTED if k % 2 else DEFAULT_CAMERA_POSE)
+                            for k in range(int(os.environ.get('ROPE_SHIM_SEEDS', '0')))])
 def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculate, pose):
     rb = helpers.robot()
     lim = rb.joint_limits
