@@ -161,3 +161,21 @@ def test_robot_from_plain_meshes_gives_the_same_results(scene):
             assert np.array_equal(sums, want_sums) and np.array_equal(err.view(np.uint64), want_err.view(np.uint64))
         finally:
             e.set_robot(rb)
+
+
+def test_robot_mesh_entry_point_rejects_broken_meshes(scene):
+    import copy
+    rb, e = scene[0], scene[4]
+    bad = copy.copy(rb)
+    bad.faces = rb.faces.copy()
+    bad.faces[7, 2] = 10 ** 6                                   # an index outside its link's vertices
+    with pytest.raises(eng.EngineError, match='indexes outside'):
+        e.set_robot_mesh(bad)
+    bad.faces = rb.faces
+    bad.vtx_off = rb.vtx_off.copy()
+    bad.vtx_off[3] = bad.vtx_off[2]                             # an empty link
+    with pytest.raises(eng.EngineError, match='empty'):
+        e.set_robot_mesh(bad)
+    e.set_robot(rb)                                             # the context is still usable
+    depth, ids = e.render(np.zeros(6), 6)
+    assert (ids != 255).any()
