@@ -203,13 +203,16 @@ int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);
  * ms[2] = raster+score launch, ms[3] = finalize+argmin, ms[4] = whole pass (averages per pass, milliseconds). */
 int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop, int reps, float *ms);
 
-/* Profiling aid, never used by the product path: bit mask of kernel phases to skip
- * (1 meshlet culling onward, 2 vertex shading onward, 4 triangle set-up, 8 pixel loop, 16 loss pass,
+/* Execution strategy: how a batch is laid out over launches.  Every value gives bit-identical results (the depth test is
+ * a minimum and the sums are exact integers); the equivalence tests and the "unshared" bench figure use it.
+ *   1  do not share links 0-2 between candidates with equal (q0, q1): six links drawn per candidate
+ *   2  do not split the meshlets of a tile over several workgroups for small batches
+ *   4  no second level of sharing (links 0-1 per distinct q0) */
+enum { ROPE_STRATEGY_NO_LAYERS = 1, ROPE_STRATEGY_NO_SPLIT = 2, ROPE_STRATEGY_NO_PARENTS = 4 };
+int rope_set_strategy(rope_ctx *ctx, int flags);
 
- * 32 small-triangle loops, 64 row pass, 128 disables shared upstream layers, 1024 disables the small-batch split,
- * 2048 disables the second level of layer sharing — results stay exact for 128, 1024 and 2048).
- * Results are meaningless while a bit is set. */
-int rope_debug_skip(rope_ctx *ctx, int mask);
+/* Phase-skipping switches for kernel ablations (rope_debug_skip) exist only in the profiling build of the library
+ * (librope_hip_profile.so, `python tools/build_variants.py profile`, -DROPE_PROFILE); this library does not export them. */
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,9 @@ def camfull_sums(depth_f32, ids, tq, link_planes):
     s[2] = sqrt_q32(dq[nz]).sum(dtype=np.uint64)
     for l in range(6):
         M = ((link_planes[l] >> np.uint64(40)) & np.uint64(1)).astype(bool)
-        R = ids == l
+        # render_color[..., 0] == color_dict[link][0] (:943-946): base_link's blue value 0 is the background's as well
+        # (constants.py:82-89), so its render mask holds every empty pixel too; depth is 0 there, the depth term is unchanged
+        R = (ids == l) | (ids == 255) if l == 0 else ids == l
         a = link_planes[l] & MASK39
         b = np.where(R, zq, np.uint64(0))
         dl = np.where(a > b, a - b, b - a)

@@ -58,6 +58,9 @@ struct rope_ctx {
     double *h_cand = nullptr, *d_cand_host = nullptr;
     const double *cand_dev = nullptr;                  // where the resident candidates are: d_cand or d_cand_host
     bool err_on_host = false;
+    // rope_eval_views / rope_lookup_score reuse C and the per-candidate buffers for rows of their own: after them the
+    // resident candidates (and the results of the last eval) are gone until rope_candidates_upload / the next eval
+    bool cand_valid = false, results_valid = false;
     float *d_mvp = nullptr;
     short4 *d_bounds = nullptr;
     uint32_t *d_mask_lo = nullptr, *d_mask_hi = nullptr;
@@ -84,12 +87,17 @@ struct rope_ctx {
     size_t gtile_cap = 0;
     bool gtile_dirty = true;
     int split_target = 6144, split_cap = 32;   // workgroups aimed at per launch / most workgroups per (tile, candidate)
+    int strategy = 0;                          // STRATEGY_* bits (rope_set_strategy): launch structure only, never a result
 
     // stored lookup table (cropped sqrt-depth of a pose grid)
     float *d_table = nullptr;
     size_t table_cap = 0;
     int table_C = 0, table_crop[4] = {0, 0, 0, 0};
     uint64_t *d_zero_total = nullptr;
+    // scores of the table's rows: buffers of their own (a grid may hold more rows than one candidate batch)
+    uint64_t *d_tsums = nullptr;
+    double *d_terr = nullptr;
+    int tscore_cap = 0;
 
     // camera-pose path: frames (joint vector + target planes each) scored under candidate views
     int n_frames = 0;
@@ -213,7 +221,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_zero_total, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_zero_total, c->d_tsums, c->d_terr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -309,20 +317,18 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const bool resized = !c->have_camera || W != c->fp.W || H != c->fp.H;
-    c->fp.W = W; c->fp.H = H;
-    c->fp.tiles_x = (W + TILE_W - 1) / TILE_W;
-    c->fp.tiles_y = (H + TILE_H - 1) / TILE_H;
-    c->fp.r0 = 0; c->fp.r1 = H - 1; c->fp.c0 = 0; c->fp.c1 = W - 1;
-    c->fp.c_num = (float)(2.0 * znear * zfar);
-    c->fp.c_sum = (float)(zfar + znear);
-    c->fp.c_dif = (float)(zfar - znear);
-    c->n_tiles = c->fp.tiles_x * c->fp.tiles_y;
-    if ((c->n_tiles + 31) / 32 > MAX_MASK_WORDS) ARG_FAIL(c, "rope_set_camera: too many tiles");
-    if ((c->n_tiles + 31) / 32 != c->mask_words) { c->mask_words = (c->n_tiles + 31) / 32; c->cap = 0; c->C = 0; }
-    c->table_C = 0;                               // a stored lookup table belongs to one camera
-    HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
+    // the new geometry in locals: the context keeps describing the old image until every buffer of the new one exists
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H, n_tiles = tiles_x * tiles_y;
+    if ((n_tiles + 31) / 32 > MAX_MASK_WORDS) ARG_FAIL(c, "rope_set_camera: too many tiles");
     if (resized) {
-        size_t n = (size_t)W * H;
+        // a failed allocation below must not leave old-sized (or freed) buffers behind a camera that looks usable:
+        // the context has no camera, no target and no frames until this call has gone through
+        c->have_camera = false;
+        c->have_target = false;
+        c->n_frames = 0;
+        c->C = 0;
+        c->cand_valid = c->results_valid = false;
+        const size_t n = (size_t)W * H;
         HIP_TRY(c, realloc_dev(&c->d_tq, n));
         HIP_TRY(c, realloc_dev(&c->d_t32, n));
         HIP_TRY(c, realloc_dev(&c->d_key, n));
@@ -330,13 +336,22 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
         HIP_TRY(c, realloc_dev(&c->d_ids, n));
         HIP_TRY(c, realloc_dev(&c->d_cover, n));
         for (int k = 0; k < 4; k++) {
-            HIP_TRY(c, realloc_dev(&c->d_empty[k], (size_t)c->n_tiles * ROPE_SUM_WORDS));
+            HIP_TRY(c, realloc_dev(&c->d_empty[k], (size_t)n_tiles * ROPE_SUM_WORDS));
             HIP_TRY(c, realloc_dev(&c->d_total[k], (size_t)ROPE_SUM_WORDS));
             c->empty_version[k] = 0;
         }
-        c->have_target = false;
-        c->n_frames = 0;
     }
+    HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
+    c->fp.W = W; c->fp.H = H;
+    c->fp.tiles_x = tiles_x;
+    c->fp.tiles_y = tiles_y;
+    c->fp.r0 = 0; c->fp.r1 = H - 1; c->fp.c0 = 0; c->fp.c1 = W - 1;
+    c->fp.c_num = (float)(2.0 * znear * zfar);
+    c->fp.c_sum = (float)(zfar + znear);
+    c->fp.c_dif = (float)(zfar - znear);
+    c->n_tiles = n_tiles;
+    if ((n_tiles + 31) / 32 != c->mask_words) { c->mask_words = (n_tiles + 31) / 32; c->cap = 0; c->C = 0; c->cand_valid = c->results_valid = false; }
+    c->table_C = 0;                               // a stored lookup table belongs to one camera
     c->have_camera = true;
     return ROPE_OK;
 }
@@ -501,13 +516,15 @@ static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
         }
     }
     c->C = C;
+    c->cand_valid = true;
+    c->results_valid = false;
     return ROPE_OK;
 }
 
 static int check_eval_args(rope_ctx *c, int n_render, int loss, const int32_t *crop, FrameParams &fp, double &n_pix)
 {
     if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "eval: robot and camera must be set first");
-    if (c->C < 1) ARG_FAIL(c, "eval: no candidates uploaded");
+    if (c->C < 1 || !c->cand_valid) ARG_FAIL(c, "eval: no candidates resident (upload them again after rope_eval_views)");
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "eval: n_render out of range");
     if (loss < 0 || loss > 3) ARG_FAIL(c, "eval: unknown loss");
     if (!c->have_target) ARG_FAIL(c, "eval: no target set");
@@ -555,7 +572,7 @@ static bool want_parents(const rope_ctx *c) { return c->n_parents * 4 <= c->n_la
 static int enqueue_layers(rope_ctx *c, RasterArgs la, int loss, int n_shared, const FrameParams &fp)
 {
     la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
-    if (n_shared == 3 && want_parents(c) && !(fp.debug & 2048)) {
+    if (n_shared == 3 && want_parents(c) && !(c->strategy & STRATEGY_NO_PARENTS)) {
         const size_t need = (size_t)c->n_parents * c->n_tiles * (TILE_W * TILE_H);
         if (need > c->parents_cap) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -602,7 +619,7 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
                         hipEvent_t *ev /* 5 events or nullptr */, bool views = false)
 {
-    const bool layers = !views && want_layers(c) && !(fp.debug & 128);
+    const bool layers = !views && want_layers(c) && !(c->strategy & STRATEGY_NO_LAYERS);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
@@ -612,7 +629,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     // Few candidates (descent pairs, flips): one workgroup per (tile, candidate) would leave most of the chip idle,
     // so the meshlets of each tile are split over several workgroups that merge into a tile in global memory.
     int split = 1;
-    if (!layers && !(fp.debug & 1024)) {
+    if (!layers && !(c->strategy & STRATEGY_NO_SPLIT)) {
         split = std::min(c->split_cap, c->split_target / std::max(1, c->C * c->n_tiles));
         if (split < 2) split = 1;
     }
@@ -626,7 +643,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         }
         // the scoring kernel hands the buffer back "empty"; clear it only when new, after a failed pass, or when a
         // profiling flag may have skipped that kernel's work
-        if (c->gtile_dirty || fp.debug) HIP_TRY(c, hipMemsetAsync(c->d_gtile, 0xFF, c->gtile_cap * sizeof(uint32_t), c->stream));
+        if (c->gtile_dirty || ROPE_SKIP(fp, ~0)) HIP_TRY(c, hipMemsetAsync(c->d_gtile, 0xFF, c->gtile_cap * sizeof(uint32_t), c->stream));
         c->gtile_dirty = true;
         RasterArgs sa = a;
         sa.split = split; sa.gtile = c->d_gtile;
@@ -646,7 +663,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         int slices = 1;
         while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->split_target) slices *= 2;
         HIP_TRY(c, launch_score_gtile(loss, c->C, slices, c->stream, fp, a));
-        c->gtile_dirty = (fp.debug != 0);
+        c->gtile_dirty = ROPE_SKIP(fp, ~0);
     } else {
         HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
     }
@@ -657,6 +674,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
                                c->err_on_host ? c->d_err_host : c->d_err));
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     c->last_n_render = n_render;
+    c->results_valid = true;
     return ROPE_OK;
 }
 
@@ -683,7 +701,7 @@ extern "C" int rope_sync(rope_ctx *c)
 extern "C" int rope_results_download(rope_ctx *c, double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err)
 {
     if (!c) return ROPE_E_ARG;
-    if (c->C < 1) ARG_FAIL(c, "rope_results_download: nothing evaluated");
+    if (c->C < 1 || !c->results_valid) ARG_FAIL(c, "rope_results_download: nothing evaluated (results do not survive rope_eval_views / rope_lookup_score / a new upload)");
     HIP_TRY(c, hipSetDevice(c->device));
     // one copy brings the errors, the best error and the best index (pinned staging)
     const double *res = c->err_on_host ? c->h_err : c->h_stage;
@@ -696,14 +714,40 @@ extern "C" int rope_results_download(rope_ctx *c, double *err_out, uint64_t *sum
     return ROPE_OK;
 }
 
+// One batch is at most MAX_ROWS candidates (the grid's y dimension).
+static constexpr int MAX_ROWS = 65535;
+
 extern "C" int rope_eval(rope_ctx *c, const double *cand, int C, int n_render, int loss, const int32_t *crop,
                          double *err_out, uint64_t *sums_out, int32_t *best_idx, double *best_err)
 {
-    int rc = rope_candidates_upload(c, cand, C);
-    if (rc) return rc;
-    rc = rope_eval_resident(c, n_render, loss, crop);
-    if (rc) return rc;
-    return rope_results_download(c, err_out, sums_out, best_idx, best_err);
+    if (!c) return ROPE_E_ARG;
+    if (C <= MAX_ROWS) {
+        int rc = rope_candidates_upload(c, cand, C);
+        if (rc) return rc;
+        rc = rope_eval_resident(c, n_render, loss, crop);
+        if (rc) return rc;
+        return rope_results_download(c, err_out, sums_out, best_idx, best_err);
+    }
+    // larger sets (lookup grids up to 200 divisions per joint, lookup.py:50): batch after batch, the argmin merged by the
+    // rule of finalize_argmin_kernel — first index of the smallest error, a NaN never beats a number
+    if (!cand) ARG_FAIL(c, "rope_eval: null candidates");
+    int32_t best = -1;
+    double be = 0.0;
+    for (int lo = 0; lo < C; lo += MAX_ROWS) {
+        const int n = std::min(MAX_ROWS, C - lo);
+        int rc = rope_candidates_upload(c, cand + 6 * (size_t)lo, n);
+        if (rc) return rc;
+        rc = rope_eval_resident(c, n_render, loss, crop);
+        if (rc) return rc;
+        int32_t bi = 0;
+        double e = 0.0;
+        rc = rope_results_download(c, err_out ? err_out + lo : nullptr, sums_out ? sums_out + (size_t)lo * ROPE_SUM_WORDS : nullptr, &bi, &e);
+        if (rc) return rc;
+        if (best < 0 || e < be || (be != be && e == e)) { best = lo + bi; be = e; }
+    }
+    if (best_idx) *best_idx = best;
+    if (best_err) *best_err = be;
+    return ROPE_OK;
 }
 
 static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int mode)
@@ -754,18 +798,25 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
 {
     if (!c) return ROPE_E_ARG;
     if (!cand || !crop) ARG_FAIL(c, "rope_lookup_build: null pointer");
+    if (C < 1) ARG_FAIL(c, "rope_lookup_build: empty grid");
     if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "rope_lookup_build: robot and camera must be set first");
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "rope_lookup_build: n_render out of range");
     if (crop[0] < 0 || crop[1] >= c->fp.H || crop[0] > crop[1] || crop[2] < 0 || crop[3] >= c->fp.W || crop[2] > crop[3])
         ARG_FAIL(c, "rope_lookup_build: crop outside the image");
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = rope_candidates_upload(c, cand, C);
-    if (rc) return rc;
+    c->table_C = 0;
     const size_t px = (size_t)(crop[1] - crop[0] + 1) * (size_t)(crop[3] - crop[2] + 1), need = px * (size_t)C;
     if (need > c->table_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, realloc_dev(&c->d_table, need));
         c->table_cap = need;
+    }
+    if (C > c->tscore_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->tscore_cap = 0;
+        HIP_TRY(c, realloc_dev(&c->d_tsums, (size_t)C * ROPE_SUM_WORDS));
+        HIP_TRY(c, realloc_dev(&c->d_terr, (size_t)C + 2));
+        c->tscore_cap = C;
     }
     if (!c->d_zero_total) {
         HIP_TRY(c, hipMalloc((void **)&c->d_zero_total, ROPE_SUM_WORDS * sizeof(uint64_t)));
@@ -774,21 +825,28 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
     HIP_TRY(c, hipMemsetAsync(c->d_table, 0, need * sizeof(float), c->stream));
     FrameParams fp = c->fp;
     fp.r0 = crop[0]; fp.r1 = crop[1]; fp.c0 = crop[2]; fp.c1 = crop[3];
-    const bool layers = want_layers(c);
-    const int n_shared = layers ? std::min(3, n_render) : 0;
-    if (layers) { rc = ensure_layers(c); if (rc) return rc; }
-    rc = enqueue_geometry(c, n_render, n_shared, fp, false);
-    if (rc) return rc;
-    RasterArgs a = base_args(c, n_render);
-    if (layers) {
-        // layer pass without loss sums (layer_sums == nullptr): no target is needed to build a table
-        rc = enqueue_layers(c, a, ROPE_LOSS_DEPTH, n_shared, c->fp);
+    // the reference allows 200 divisions per joint (lookup.py:50, constants.py:30): more rows than one batch holds, so the
+    // grid is rendered batch after batch into its rows of the table
+    for (int lo = 0; lo < C; lo += MAX_ROWS) {
+        const int n = std::min(MAX_ROWS, C - lo);
+        int rc = rope_candidates_upload(c, cand + 6 * (size_t)lo, n);
         if (rc) return rc;
-        a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers;
+        const bool layers = want_layers(c);
+        const int n_shared = layers ? std::min(3, n_render) : 0;
+        if (layers) { rc = ensure_layers(c); if (rc) return rc; }
+        rc = enqueue_geometry(c, n_render, n_shared, fp, false);
+        if (rc) return rc;
+        RasterArgs a = base_args(c, n_render);
+        if (layers) {
+            // layer pass without loss sums (layer_sums == nullptr): no target is needed to build a table
+            rc = enqueue_layers(c, a, ROPE_LOSS_DEPTH, n_shared, c->fp);
+            if (rc) return rc;
+            a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers;
+        }
+        a.table = c->d_table + (size_t)lo * px;
+        HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    a.table = c->d_table;
-    HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->table_C = C;
     std::memcpy(c->table_crop, crop, 4 * sizeof(int32_t));
     return ROPE_OK;
@@ -799,18 +857,18 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     if (!c) return ROPE_E_ARG;
     if (c->table_C < 1) ARG_FAIL(c, "rope_lookup_score: no table built");
     if (!c->have_target || !c->have_t32) ARG_FAIL(c, "rope_lookup_score: needs a target with the float32 plane");
-    if (c->table_C > c->cap) ARG_FAIL(c, "rope_lookup_score: result buffers were resized; rebuild the table");
     HIP_TRY(c, hipSetDevice(c->device));
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
-    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_depth /* scratch: H x W floats */, c->d_sums));
-    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_err));
-    if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_err, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err + c->table_C, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_depth /* scratch: H x W floats */, c->d_tsums));
+    HIP_TRY(c, launch_finalize(c->stream, c->d_tsums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_terr));
+    if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_terr, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    double tail[2];
+    HIP_TRY(c, hipMemcpyAsync(tail, c->d_terr + c->table_C, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (best_score) *best_score = c->h_stage[0];
-    if (best_idx) *best_idx = (int32_t)c->h_stage[1];
+    if (best_score) *best_score = tail[0];
+    if (best_idx) *best_idx = (int32_t)tail[1];
     return ROPE_OK;
 }
 
@@ -894,6 +952,9 @@ extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_rende
     c->dv_view_of = reinterpret_cast<const int32_t *>(c->d_vstage + off_vo);
     c->dv_frame_of = reinterpret_cast<const int32_t *>(c->d_vstage + off_fo);
     c->C = C;
+    c->cand_valid = false;                            // the rows are (view, frame) pairs now: cand_dev / err_on_host describe nothing
+    c->results_valid = false;
+    c->cand_dev = nullptr;
     c->n_layers = C;                                  // every (view, frame) candidate is its own layer: nothing shared
     const size_t plane = (size_t)c->fp.W * c->fp.H;
     uint64_t *ftotal = c->d_ftotal + (size_t)loss * c->ftotal_cap * ROPE_SUM_WORDS;     // one block of totals per loss kind
@@ -941,12 +1002,22 @@ extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
     return ROPE_OK;
 }
 
+extern "C" int rope_set_strategy(rope_ctx *c, int flags)
+{
+    if (!c) return ROPE_E_ARG;
+    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
+    c->strategy = flags;
+    return ROPE_OK;
+}
+
+#ifdef ROPE_PROFILE
 extern "C" int rope_debug_skip(rope_ctx *c, int mask)
 {
     if (!c) return ROPE_E_ARG;
     c->fp.debug = mask;
     return ROPE_OK;
 }
+#endif
 
 extern "C" int rope_profile_eval(rope_ctx *c, int n_render, int loss, const int32_t *crop, int reps, float *ms)
 {

@@ -55,8 +55,21 @@ struct FrameParams {
     int W, H, tiles_x, tiles_y;
     int r0, r1, c0, c1;                   // rows/cols taking part in the loss (whole frame unless lookup crop)
     float c_num, c_sum, c_dif;            // 2nf, f+n, f-n as float32 (pyrender depth read-back)
-    int debug;                            // profiling only: bit mask of phases to skip (0 in production)
+#ifdef ROPE_PROFILE
+    int debug;                            // librope_hip_profile.so only: bit mask of kernel phases to skip (rope_debug_skip)
+#endif
 };
+
+// Phase-skipping switches exist only in the profiling build (tools/build_variants.py, -DROPE_PROFILE): the shipped
+// library has neither the branches nor rope_debug_skip.
+#ifdef ROPE_PROFILE
+#define ROPE_SKIP(fp, bit) (((fp).debug & (bit)) != 0)
+#else
+#define ROPE_SKIP(fp, bit) false
+#endif
+
+// Execution strategies that change the launch structure but never a result (rope_set_strategy)
+enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4 };
 
 struct RobotParams {
     const uint32_t *ml_header;            // n_meshlets x 8

@@ -204,7 +204,9 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
         for (int l = 0; l < ROPE_MAX_LINKS; l++) {
             if (l < n_render) {
                 const uint64_t tll = tl[(size_t)l * plane + pix];
-                const bool M = (tll >> 40) & 1, R = (id == l);
+                // the reference compares blue values (:943-946), and base_link's blue is 0 — the black background's too
+                // (constants.py:82-89): its render mask also holds every pixel nothing was drawn on
+                const bool M = (tll >> 40) & 1, R = (id == l) || (l == 0 && empty);
                 if (!M && !R && !(tll & 0x7FFFFFFFFFull)) continue;
                 const uint64_t a = tll & 0x7FFFFFFFFFull, b = R ? zq : 0;
                 const uint64_t dl = a > b ? a - b : b - a;
@@ -703,7 +705,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     const size_t mw_lo = (MODE != MODE_LAYER && ra.layer_of) ? (size_t)ra.layer_rep[ra.layer_of[cand]] * ra.mask_words + (tile_id >> 5) : mw;
     const bool hit_lo = (ra.mask_lo[mw_lo] >> (tile_id & 31)) & 1u, hit_hi = (ra.mask_hi[mw] >> (tile_id & 31)) & 1u;
     if (MODE == MODE_LAYER ? !hit_lo : !(hit_lo || hit_hi)) return;
-    if (fp.debug & 1) return;
+    if (ROPE_SKIP(fp, 1)) return;
     // shared layer (links below l_begin, rendered once per distinct upstream pose) covering this tile
     const uint32_t *layer_tile = nullptr;
     if (MODE != MODE_LAYER && ra.layer_of && hit_lo)
@@ -812,7 +814,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
                                 }
                         } else if (w <= SMALL_TRI_COLS && h <= SMALL_TRI_ROWS) {
                             // small box: walk its rows, four samples of a row at a time without branching on coverage tests
-                            if (!(fp.debug & 32)) {
+                            if (!ROPE_SKIP(fp, 32)) {
                                 const int u0 = x0 - col0;
                                 const int vv = y0 - tf.vy0;       // coefficients are below 2^22 here, u0 and vv below 2^8
                                 int t0 = __mul24(e0.A, u0) + __mul24(e0.B, vv), t1 = __mul24(e1.A, u0) + __mul24(e1.B, vv),
@@ -850,7 +852,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
             // order, so a scan of `rows` over the lanes gives every queued triangle its first item; the
             // owner of an item is found from a per-chunk bit mask of "a triangle starts at this item".
             const unsigned long long qmask = __ballot(rows > 0);
-            if (qmask == 0 || (fp.debug & 64)) return;
+            if (qmask == 0 || ROPE_SKIP(fp, 64)) return;
             int incl = rows;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -919,7 +921,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
         const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
         const uint32_t l = h1.w;
-        if (fp.debug & 2) continue;
+        if (ROPE_SKIP(fp, 2)) continue;
         {
             // the link matrix is the same for the whole wave: keep it in scalar registers
             float mm[16];
@@ -935,7 +937,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (fp.debug & 4) continue;
+        if (ROPE_SKIP(fp, 4)) continue;
         // ---- pass 1: cull.  Keep front-facing triangles whose bounding box holds a sample of this tile and
         // compact them, so that the expensive set-up below runs on full lanes (about one triangle in four survives).
         int ns = 0;
@@ -967,7 +969,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (fp.debug & 8) continue;
+        if (ROPE_SKIP(fp, 8)) continue;
         // ---- hand the survivors to free lanes of the pending batch; pass 2 runs whenever 64 are waiting, so that the
         // expensive set-up and the pixel work execute on full waves (survivors of several meshlets share a batch)
         for (int taken = 0; taken < ns;) {
@@ -1050,7 +1052,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         }
         return;
     }
-    if (fp.debug & 16) return;
+    if (ROPE_SKIP(fp, 16)) return;
     score_tile<LOSS, true>(tile, layer_tile, row0, col0, fp, n_render, tq, t32, tl, lds_sums, rc);
     __syncthreads();
     if (tid < ROPE_SUM_WORDS) {
@@ -1082,7 +1084,7 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
     const TileRect rc = {(int)blockIdx.z * rows, (int)blockIdx.z * rows + rows - 1, 0, TILE_W / 4 - 1, 4};   // 16 groups x 4 rows (bands are multiples of 4 rows)
     uint32_t *g = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
     const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
-    if (!(fp.debug & 16)) score_tile<LOSS, true>(g, nullptr, ty * TILE_H, tx * TILE_W, fp, ra.n_render, tq, t32, tl, lds_sums, rc);
+    if (!ROPE_SKIP(fp, 16)) score_tile<LOSS, true>(g, nullptr, ty * TILE_H, tx * TILE_W, fp, ra.n_render, tq, t32, tl, lds_sums, rc);
     __syncthreads();
     uint4 *g4 = reinterpret_cast<uint4 *>(g) + rc.r_lo * (TILE_W / 4);
     for (int i = tid; i < rows * (TILE_W / 4); i += blockDim.x) {

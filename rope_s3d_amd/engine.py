@@ -20,7 +20,7 @@ TQ_MAX = (1 << 39) - 1
 ABI_SYMBOLS = (
     'rope_create', 'rope_destroy', 'rope_last_error', 'rope_set_robot', 'rope_set_camera', 'rope_set_target',
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
-    'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_debug_skip',
+    'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_set_strategy',
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even')
 
 
@@ -84,7 +84,9 @@ def load_library(path: str = None):
     lib.rope_coverage.argtypes = [vp, vp, i32, i32, vp]
     lib.rope_debug_mvp.argtypes = [vp, vp, i32, i32]
     lib.rope_profile_eval.argtypes = [vp, i32, i32, vp, i32, vp]
-    lib.rope_debug_skip.argtypes = [vp, i32]
+    lib.rope_set_strategy.argtypes = [vp, i32]
+    if hasattr(lib, 'rope_debug_skip'):                 # librope_hip_profile.so only (ROPE_HIP_LIB=...)
+        lib.rope_debug_skip.argtypes = [vp, i32]
     lib.rope_predict.argtypes = [vp, C.POINTER(PredictArgs), vp, vp, C.POINTER(C.c_int64)]
     lib.rope_set_robot_mesh.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     lib.rope_partition_mesh.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
@@ -319,7 +321,17 @@ class Engine:
         self._check(self._lib.rope_debug_mvp(self._ctx, _p(out), int(C_), int(n_render)), 'rope_debug_mvp')
         return out
 
+    NO_LAYERS, NO_SPLIT, NO_PARENTS = 1, 2, 4
+
+    def set_strategy(self, flags: int):
+        """rope_set_strategy: launch structure only (shared layers / small-batch split / second sharing level off);
+        results are bit-identical for every value."""
+        self._check(self._lib.rope_set_strategy(self._ctx, int(flags)), 'rope_set_strategy')
+
     def debug_skip(self, mask: int):
+        """Kernel-phase ablation; only the profiling build of the library has it (tools/build_variants.py profile)."""
+        if not hasattr(self._lib, 'rope_debug_skip'):
+            raise EngineError("rope_debug_skip: not in this library; build librope_hip_profile.so and point ROPE_HIP_LIB at it")
         self._check(self._lib.rope_debug_skip(self._ctx, int(mask)), 'rope_debug_skip')
 
     def profile_eval(self, n_render: int, loss: int, crop=None, reps: int = 10):

@@ -68,8 +68,14 @@ def test_integer_sums_track_the_literal_reductions():
     ref = camera_ref.CameraReference(o, P, 'modelless', qs, tgt)
     assert abs(ref.error(pose) - camera_ref.modelless_error_literal(depth, tgt)) < 1e-6
     ref = camera_ref.CameraReference(o, P, 'segmented', qs, tgt, seg, names)
-    blue = {n: l for l, n in enumerate(names)}                 # any injective labelling: use the link id itself
-    want = camera_ref.camfull_error_literal(rid, depth.astype(np.float64), tgt, ref.masked_targets, ref.target_masks, names, blue)
+    # the reference's own labels: channel 0 of DEFAULT_RENDER_COLORS per link, and 0 where nothing was drawn (render.py:52) —
+    # base_link's value 0 equals the background's (constants.py:82-89), so its render mask covers every empty pixel as well
+    from rope_s3d_amd.constants import DEFAULT_RENDER_COLORS
+    blue = {n: DEFAULT_RENDER_COLORS[l][0] for l, n in enumerate(names)}
+    assert blue[names[0]] == 0 and len(set(blue.values())) == 6
+    lut = np.zeros(256, np.int64)
+    lut[:6] = [DEFAULT_RENDER_COLORS[l][0] for l in range(6)]        # id 255 (empty) -> 0, the black background
+    want = camera_ref.camfull_error_literal(lut[rid], depth.astype(np.float64), tgt, ref.masked_targets, ref.target_masks, names, blue)
     got = ref.error(pose)
     assert abs(got - want) < 1e-6 * max(1.0, abs(want))
     assert abs(ref.sweep_error(pose) - camera_ref.pooled_sweep_literal(depth, tgt)) < 1e-6

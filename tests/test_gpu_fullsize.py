@@ -60,12 +60,12 @@ def test_full_grid_layers_equal_direct_rendering(full):
     cand = helpers.slu_grid(rb.joint_limits, 16)
     for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL):
         _, sums_a, bi_a, _ = e.eval(cand, 6, loss, want_sums=True)
-        for flag in (128, 2048):                       # no shared layers at all; layers without the second level (per q0)
-            e.debug_skip(flag)
+        for flag in (e.NO_LAYERS, e.NO_PARENTS):                       # no shared layers at all; layers without the second level (per q0)
+            e.set_strategy(flag)
             try:
                 _, sums_b, bi_b, _ = e.eval(cand, 6, loss, want_sums=True)
             finally:
-                e.debug_skip(0)
+                e.set_strategy(0)
             assert np.array_equal(sums_a, sums_b) and bi_a == bi_b, (loss, flag)
     # a grid whose first joint takes few values and the second many: parents with many layers each, and n_render = 4
     grid = np.zeros((3 * 40 * 4, 6))
@@ -74,11 +74,11 @@ def test_full_grid_layers_equal_direct_rendering(full):
     grid = grid[np.random.default_rng(5).permutation(len(grid))]
     for n in (4, 6):
         _, sums_a, bi_a, _ = e.eval(grid, n, eng.LOSS_FULL, want_sums=True)
-        e.debug_skip(128)
+        e.set_strategy(e.NO_LAYERS)
         try:
             _, sums_b, bi_b, _ = e.eval(grid, n, eng.LOSS_FULL, want_sums=True)
         finally:
-            e.debug_skip(0)
+            e.set_strategy(0)
         assert np.array_equal(sums_a, sums_b) and bi_a == bi_b, n
 
 
@@ -177,6 +177,23 @@ def test_abi_rejects_bad_calls():
         e.set_target(np.zeros((3, 3), np.uint64))
     e.eval_resident(6, eng.LOSS_DEPTH)                              # still usable after the refused calls
     e.sync()
+    # rope_eval_views reuses the per-candidate buffers for (view, frame) rows: the resident candidates and the last results
+    # are gone after it, and saying so beats reading a 256-row mapped block (or NULL) with C = K*N rows
+    err0 = e.download()[0]
+    H, W = intr.height, intr.width
+    e.set_frames(np.zeros((300, 6)), np.zeros((300, H, W), np.uint64))
+    e.eval_views(np.stack([PV]), 6, eng.LOSS_DEPTH)
+    with pytest.raises(eng.EngineError):
+        e.eval_resident(6, eng.LOSS_DEPTH)
+    with pytest.raises(eng.EngineError):
+        e.profile_eval(6, eng.LOSS_DEPTH, None, reps=1)
+    with pytest.raises(eng.EngineError):
+        e.download()
+    e.upload_candidates(np.zeros((4, 6)))
+    with pytest.raises(eng.EngineError):
+        e.download()                                                # new candidates, nothing evaluated yet
+    e.eval_resident(6, eng.LOSS_DEPTH)
+    assert np.array_equal(e.download()[0].view(np.uint64), err0.view(np.uint64))
 
 
 def test_more_candidates_than_one_launch_holds():
@@ -191,6 +208,32 @@ def test_more_candidates_than_one_launch_holds():
     ref, _, bi0, be0 = e.eval(base, 6, eng.LOSS_DEPTH)
     assert err.shape == (70000,) and np.array_equal(err.reshape(70, 1000).view(np.uint64), np.tile(ref.view(np.uint64), (70, 1)))
     assert bi == bi0 and be == be0                                     # first occurrence wins across launches too
+
+
+def test_lookup_grid_beyond_one_launch():
+    """41^3 = 68 921 grid poses (the reference allows 200 divisions per joint, lookup.py:50, constants.py:30): the stored
+    table is built batch after batch, and both the table scores and the on-the-fly lookup loss through one rope_eval call
+    equal the batched Python evaluation row for row."""
+    import ctypes as C
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '640_480_color', ds=8)
+    d, ids = e.render([0.3, 0.4, 0.9, 0, 0, 0], 6)
+    tq, t32, flags = helpers.synthetic_target(d, ids)[:3]
+    e.set_target(tq, t32, flags)
+    grid = helpers.slu_grid(rb.joint_limits, 41)
+    assert len(grid) == 68921 > e.MAX_BATCH
+    crop = [5, intr.height - 4, 7, intr.width - 6]
+    want, _, bi0, be0 = e.eval(grid, 6, eng.LOSS_LOOKUP, crop)          # Python-side batches of <= 65 535 rows
+    e.lookup_build(grid, 6, crop)
+    scores, bi, be = e.lookup_score(want_scores=True)
+    assert np.array_equal(scores.view(np.uint64), want.view(np.uint64)) and (bi, be) == (bi0, be0)
+    # the same rows through ONE call across the C boundary (what rope_predict's Lookup stage does without a table)
+    err = np.empty(len(grid))
+    bi1, be1 = C.c_int32(), C.c_double()
+    crop_a = np.ascontiguousarray(crop, np.int32)
+    rc = e._lib.rope_eval(e._ctx, grid.ctypes.data_as(C.c_void_p), len(grid), 6, eng.LOSS_LOOKUP, crop_a.ctypes.data_as(C.c_void_p),
+                          err.ctypes.data_as(C.c_void_p), None, C.byref(bi1), C.byref(be1))
+    assert rc == 0 and np.array_equal(err.view(np.uint64), want.view(np.uint64)) and (bi1.value, be1.value) == (bi0, be0)
 
 
 @pytest.mark.parametrize('seed', list(range(1, 1 + int(__import__('os').environ.get('ROPE_FUZZ_SEEDS', '12')))))

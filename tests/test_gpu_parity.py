@@ -81,11 +81,11 @@ def test_shared_layers_do_not_change_results(scene):
     cand = helpers.slu_grid(rb.joint_limits, 5)            # 125 candidates, 25 distinct (S, L) prefixes
     for loss, n in ((eng.LOSS_FULL, 6), (eng.LOSS_FULL, 2), (eng.LOSS_DEPTH, 4)):
         err_a, sums_a, bi_a, _ = e.eval(cand, n, loss, want_sums=True)
-        e.debug_skip(128)
+        e.set_strategy(e.NO_LAYERS)
         try:
             err_b, sums_b, bi_b, _ = e.eval(cand, n, loss, want_sums=True)
         finally:
-            e.debug_skip(0)
+            e.set_strategy(0)
         assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
         err_ref = o.eval(cand[::7], loss, n, tq, t32, None, flags, threads=8)
         assert np.array_equal(err_a[::7].view(np.uint64), err_ref.view(np.uint64))
@@ -122,11 +122,11 @@ def test_small_batch_split_does_not_change_results(scene):
     for n_c in (1, 2, 6):
         for loss, n in ((eng.LOSS_FULL, 6), (eng.LOSS_FULL, 4), (eng.LOSS_DEPTH, 6)):
             err_a, sums_a, bi_a, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
-            e.debug_skip(1024)
+            e.set_strategy(e.NO_SPLIT)
             try:
                 err_b, sums_b, bi_b, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
             finally:
-                e.debug_skip(0)
+                e.set_strategy(0)
             assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
             ref = o.eval(cand[:n_c], loss, n, tq, t32, None, flags, threads=4)
             assert np.array_equal(err_a.view(np.uint64), ref.view(np.uint64))

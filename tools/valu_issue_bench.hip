@@ -1,0 +1,150 @@
+// valu_issue_bench.hip — what one SIMD of MI355X (gfx950) issues per cycle for the instruction kinds the raster kernel
+// is made of, at the raster kernel's own occupancy (768-thread workgroups, 2 per CU = 6 waves per SIMD) and at 1..8
+// waves per SIMD.  Settles the "2 or 4 cycles per wave64 VALU instruction" question the round-1 roofline left open.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/valu_issue_bench.hip -o gpurun_out/valu_issue_bench && gpurun_out/valu_issue_bench
+//
+// Every kernel runs ITER x UNROLL independent instructions of one kind per wave on private registers (eight accumulators,
+// so no dependent-issue stalls), stamped with s_memtime on both sides; cycles per wave-instruction per SIMD =
+// (cycles of the slowest wave) * waves_per_simd_resident / (waves per SIMD * instructions per wave) ... measured simply as
+// total SIMD-cycles / total wave-instructions: wall cycles of a workgroup set that fills every SIMD evenly.
+// Output: one JSON object on stdout (committed as profiles/r02_valu_issue.json).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                         \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } \
+    } while (0)
+
+constexpr int ITER = 2048, UNROLL = 8;
+
+enum Kind { K_FMA_F32 = 0, K_ADD_U32, K_MUL24, K_MUL_LO_U32, K_MAD_U64_U32, K_CNDMASK, K_RCP_F32, K_CVT_F32_I32, K_MIN3_I32, K_PK_FMA_F32, K_ADD_U64, K_MIX, N_KINDS };
+static const char *kind_name[N_KINDS] = {"v_fma_f32", "v_add_u32", "v_mul_i32_i24", "v_mul_lo_u32", "v_mad_u64_u32", "v_cndmask_b32", "v_rcp_f32",
+                                         "v_cvt_f32_i32", "v_min3_i32", "v_pk_fma_f32", "u64 add (2 x v_add_co)", "raster-like mix (fma, add, mul24, cndmask, min3, cvt; no transcendental)"};
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) issue_kernel(uint64_t *cycles, uint32_t *sink, uint32_t seed)
+{
+    uint32_t a[UNROLL];
+    float f[UNROLL];
+    uint64_t q[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; k++) { a[k] = seed + threadIdx.x * 7 + k; f[k] = (float)(a[k] & 1023) * 1.0e-3f + 1.0f; q[k] = ((uint64_t)a[k] << 20) | k; }
+    const float fb = (float)(seed & 7) * 1.0e-7f + 1.0f, fc = (float)(seed & 3) * 1.0e-9f;
+    const uint32_t ub = seed | 1u;
+    __syncthreads();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            if (KIND == K_FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[k]) : "v"(fb), "v"(fc));
+            else if (KIND == K_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(ub));
+            else if (KIND == K_MUL24) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[k]) : "v"(ub));
+            else if (KIND == K_MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(ub));
+            else if (KIND == K_MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[k]) : "v"(a[k]), "v"(ub) : "vcc");
+            else if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(ub) : "vcc");
+            else if (KIND == K_RCP_F32) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[k]));
+            else if (KIND == K_CVT_F32_I32) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[k]) : "v"(a[k]));
+            else if (KIND == K_MIN3_I32) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(ub), "v"(seed));
+            else if (KIND == K_PK_FMA_F32) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q[k]) : "v"(q[(k + 1) % UNROLL]));
+            else if (KIND == K_ADD_U64) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, 0, vcc" : "+v"(a[k]), "+v"(a[(k + 4) % UNROLL]) : "v"(ub) : "vcc");
+            else {
+                // eight instructions of the kinds the cull / set-up code is made of
+                switch (k) {
+                case 0: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[0]) : "v"(fb), "v"(fc)); break;
+                case 1: asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[1]) : "v"(ub)); break;
+                case 2: asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[2]) : "v"(ub)); break;
+                case 3: asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[3]) : "v"(ub) : "vcc"); break;
+                case 4: asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[4]) : "v"(ub), "v"(seed)); break;
+                case 5: asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[5]) : "v"(a[5])); break;
+                case 6: asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[6]) : "v"(ub)); break;
+                default: asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[7]) : "v"(fb)); break;
+                }
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < UNROLL; k++) acc ^= a[k] ^ __float_as_uint(f[k]) ^ (uint32_t)q[k] ^ (uint32_t)(q[k] >> 32);
+    if (acc == 0x12345678u) sink[0] = acc;                                   // keeps the registers alive
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND>
+static double run(int waves_per_simd, uint64_t *d_cycles, uint32_t *d_sink, std::vector<uint64_t> &h, double *wall_ms)
+{
+    // one workgroup per CU holding 4 * waves_per_simd waves, except the raster kernel's own shape for 6: 2 x 768 threads per CU
+    const int n_cu = 256;
+    int threads = 256 * waves_per_simd, blocks = n_cu;
+    if (waves_per_simd == 6) { threads = 768; blocks = 2 * n_cu; }
+    if (threads > 1024) { threads /= 2; blocks *= 2; }
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(issue_kernel<KIND>, dim3(blocks), dim3(threads), 0, 0, d_cycles, d_sink, 12345u);      // warm-up
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(issue_kernel<KIND>, dim3(blocks), dim3(threads), 0, 0, d_cycles, d_sink, 12345u);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *wall_ms = ms;
+    const int n_waves = blocks * (threads / 64);
+    CHECK(hipMemcpy(h.data(), d_cycles, n_waves * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    double mean = 0;
+    for (int i = 0; i < n_waves; i++) mean += (double)h[i];
+    mean /= n_waves;
+    // s_memtime counts at a fixed 100 MHz-derived rate?  No: on gfx950 it counts shader clock cycles (MI355X_MICROARCH.md).
+    // A wave's stream of N instructions took `mean` cycles while waves_per_simd waves shared its SIMD:
+    const double n_inst = (double)ITER * UNROLL * (KIND == K_ADD_U64 ? 2 : 1);
+    return mean / (n_inst * waves_per_simd);                                  // SIMD cycles per wave-instruction
+}
+
+template <int KIND>
+static void sweep(uint64_t *d_cycles, uint32_t *d_sink, std::vector<uint64_t> &h, bool last)
+{
+    printf("  {\"instruction\": \"%s\", \"cycles_per_wave_instruction_per_simd\": {", kind_name[KIND]);
+    const int wps[] = {1, 2, 4, 6, 8};
+    for (int i = 0; i < 5; i++) {
+        double ms;
+        const double c = run<KIND>(wps[i], d_cycles, d_sink, h, &ms);
+        printf("\"%d\": %.3f%s", wps[i], c, i < 4 ? ", " : "");
+    }
+    printf("}}%s\n", last ? "" : ",");
+}
+
+int main()
+{
+    uint64_t *d_cycles;
+    uint32_t *d_sink;
+    CHECK(hipMalloc((void **)&d_cycles, 1 << 20));
+    CHECK(hipMalloc((void **)&d_sink, 64));
+    std::vector<uint64_t> h(1 << 17);
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"iter\": %d, \"unroll\": %d,\n \"note\": \"SIMD cycles (s_memtime) per wave64 instruction with N waves resident per SIMD, "
+           "independent instructions; 6 = two 768-thread workgroups per CU, the raster kernel's occupancy\",\n \"kinds\": [\n",
+           prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, ITER, UNROLL);
+    sweep<K_FMA_F32>(d_cycles, d_sink, h, false);
+    sweep<K_ADD_U32>(d_cycles, d_sink, h, false);
+    sweep<K_MUL24>(d_cycles, d_sink, h, false);
+    sweep<K_MUL_LO_U32>(d_cycles, d_sink, h, false);
+    sweep<K_MAD_U64_U32>(d_cycles, d_sink, h, false);
+    sweep<K_CNDMASK>(d_cycles, d_sink, h, false);
+    sweep<K_RCP_F32>(d_cycles, d_sink, h, false);
+    sweep<K_CVT_F32_I32>(d_cycles, d_sink, h, false);
+    sweep<K_MIN3_I32>(d_cycles, d_sink, h, false);
+    sweep<K_PK_FMA_F32>(d_cycles, d_sink, h, false);
+    sweep<K_ADD_U64>(d_cycles, d_sink, h, false);
+    sweep<K_MIX>(d_cycles, d_sink, h, true);
+    printf(" ]}\n");
+    return 0;
+}
