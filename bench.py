@@ -13,6 +13,9 @@ exchange is one RCCL all-gather of the ranks' best joint vectors, inside the tim
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      # without WORLD_SIZE in the environment: starts the N ranks itself (same launcher)
+
+The number of ranks that took part is checked against --gpus on every rank and reported as "ranks_seen"; a mismatch is an error.
 """
 import argparse
 import json
@@ -50,6 +53,47 @@ def measured_traffic():
             return json.load(f)['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
+
+
+def measured_pmc():
+    """Per-launch PMC averages of the scoring kernel from the committed rocprofv3 passes of this round
+    (profiles/r02_pmc.json, tools/summarize_prof.py); {} if absent."""
+    for name in ('r02_pmc.json', 'r01_final_pmc.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                d = json.load(f)
+            return {k: v['avg_per_launch'] for k, v in d['counters'].items()}, name
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
+
+
+def valu_issue_peak():
+    """Wave64 VALU instructions one SIMD retires per second at the raster kernel's occupancy (6 waves per SIMD), from the
+    committed micro-benchmark (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.json): (full-rate ops, a mix of the
+    kinds the kernel is made of), wall-clock based so that the clock the chip holds under load is already in it."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_valu_issue.json')) as f:
+            kinds = {k['instruction']: k['wall_ns_per_wave_instruction_per_simd']['6'] for k in json.load(f)['kinds']}
+        mix = [v for k, v in kinds.items() if k.startswith('raster-like mix')][0]
+        return 1e9 / kinds['v_add_u32'], 1e9 / mix
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher's environment: become the launcher.  Runs before anything touches the GPU (the
+    children are fresh processes of torch.distributed.run, one rank per GPU), relays their output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None, loss=0, flags=None):
@@ -99,10 +143,18 @@ def main():
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL over xGMI); 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to "
+                         "print a line whose n_gpus would be wrong")
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -116,6 +168,10 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', device))
         else:
             dist.init_process_group(args.backend)
+
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    if ranks_seen != args.gpus:
+        raise SystemExit(f"bench.py: process group holds {ranks_seen} ranks, --gpus says {args.gpus}")
 
     from rope_s3d_amd import engine as eng
     from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
@@ -206,10 +262,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # outside the timed region: the same candidates with nothing shared between them (six links drawn per candidate) —
+    # the rate a caller sees when no two candidates agree in their first two joint angles
+    e.set_strategy(e.NO_LAYERS)
+    e.eval_resident(6, loss)
+    kern_u = e.profile_eval(6, loss, None, reps=max(2, min(args.steps, 5)))
+    e.set_strategy(0)
+
     if rank == 0:
         poses = (C_total if args.split_candidates else world * C) * args.steps
         raster_s = kern['raster'] * 1e-3
         achieved = b_cand * C / raster_s / 1e9
+        default_wl = args.loss == 'depth' and args.workload == 'cfg1' and args.grid == 16
+        traffic = measured_traffic() if default_wl else None
+        pmc, pmc_file = measured_pmc() if default_wl else ({}, None)
+        peak_full, peak_mix = valu_issue_peak()
+        n_simd = 256 * 4
+        valu = None
+        if pmc.get('SQ_INSTS_VALU') and peak_mix:
+            rate = pmc['SQ_INSTS_VALU'] / (kern['score'] * 1e-3)            # wave64 VALU instructions per second, whole chip
+            valu = {"bound": "valu_issue", "achieved": rate / 1e9, "peak": peak_mix * n_simd / 1e9, "unit": "G wave-instructions/s",
+                    "frac": rate / (peak_mix * n_simd), "peak_full_rate_ops": peak_full * n_simd / 1e9,
+                    "frac_of_full_rate_peak": rate / (peak_full * n_simd),
+                    "valu_instructions_per_launch": pmc['SQ_INSTS_VALU'], "active_lanes_of_64": pmc.get('active_lanes'),
+                    "source": f"SQ_INSTS_VALU of the scoring launch from profiles/{pmc_file} (rocprofv3 --pmc, same command) / its live launch time; "
+                              "peak = 1024 SIMDs x the rate one SIMD retires a kernel-like instruction mix at 6 waves per SIMD "
+                              "(tools/valu_issue_bench.hip, profiles/r02_valu_issue.json; wall-clock based, full-rate ops beside it)"}
         out = {
             "metric": "rendered+scored candidate poses/sec @%dx%d" % (W, H),
             "value": poses / dt, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -221,8 +299,19 @@ def main():
                        "candidates_per_step": C, "frames_per_rank": 1,
                        "parallelism": f"candidates of one frame /{world}" if args.split_candidates else f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
+            "ranks_seen": ranks_seen,
+            "unshared_value": C / (kern_u['total'] * 1e-3),
+            "unshared_note": "poses/s per GPU with rope_set_strategy(NO_LAYERS): links 0-2 drawn for every candidate instead of once "
+                             "per distinct (S, L); same results bit for bit; measured after the timed region",
+            # SURVEY §8d's contract: algorithmic bytes per candidate x candidates per launch / live launch time against the HBM
+            # peak.  The kernel keeps a candidate's depth image in LDS, so the bytes that really cross the HBM pins (`traffic`,
+            # PMC) are a small fraction of the algorithmic ones and HBM is not what binds it: see measured_hbm_* and valu_issue.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic() if (args.loss == 'depth' and args.workload == 'cfg1') else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_hbm_GBs": (traffic / (kern['score'] * 1e-3) / 1e9) if traffic else None,
+                         "measured_hbm_frac": (traffic / (kern['score'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "binding_resource": "vector instruction issue (valu_issue below), not HBM",
+                         "valu_issue": valu,
                          "kernel": "raster_score_kernel<%s,SCORE> (+ its <%s,LAYER> launches: links 0-2 once per distinct (S,L))" % ((args.loss.upper(),) * 2),
                          "kernel_ms": kern['raster'], "score_launch_ms": kern['score'], "layer_launch_ms": kern['layer'],
                          "bytes_per_candidate": b_cand, "candidates_per_launch": C,

@@ -42,3 +42,26 @@ def test_two_rank_shard_and_gather(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / 'rank0.txt').read_text() == '0 6' and (tmp_path / 'rank1.txt').read_text() == '6 11'
+
+
+def _bench(args, env_extra, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra, OMP_NUM_THREADS='1')
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_refuses_a_rank_count_that_contradicts_gpus():
+    """--gpus 8 inside a one-rank launch must not print a line saying n_gpus: 1 (round-1 finding)."""
+    out = _bench(['--gpus', '8', '--steps', '1', '--warmup', '0'], {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert out.returncode != 0 and 'refusing' in out.stderr and out.stdout.strip() == ''
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_failure():
+    """Without a launcher's environment `--gpus 2` starts two ranks itself, before anything touches a GPU.  Here there is no
+    GPU, so both children stop with the engine's refusal and the parent hands their failure on."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check; the GPU suite runs the two-rank bench for real")
+    out = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--backend', 'gloo'], {})
+    assert out.returncode != 0 and out.stderr.count('bench.py needs a GPU') >= 2, out.stderr[-2000:]

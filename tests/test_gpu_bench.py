@@ -1,0 +1,40 @@
+"""GPU: bench.py as the driver runs it — the JSON contract, and N > 1 started by bench.py itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu():
+    d = _run(['--steps', '3', '--warmup', '1', '--cpu-sample', '256'])
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['steps'] == 3 and d['unit'] == 'poses/s' and d['scaling'] == 'weak'
+    assert d['config']['candidates_per_step'] == 4096 and 'configs[1]' in d['config']['workload']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(r['achieved'] - r['bytes_per_candidate'] * 4096 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    assert d['unshared_value'] < d['value'] * 1.05                     # drawing six links per candidate is never the faster layout
+    assert d['cpu_baseline']['gpu_errors_vs_port']['identical_bits'] is True and d['cpu_baseline']['kind'] == 'port'
+
+
+def test_bench_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: two ranks (both on this box's one GPU, collectives over gloo),
+    the line says so, and the aggregate is the two ranks' work over the slower rank's time."""
+    d = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--backend', 'gloo', '--no-cpu-baseline'], {'ROPE_FORCE_DEVICE': '0'})
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['config']['parallelism'] == 'frames x2'
+    assert abs(d['value'] - 2 * 4096 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']

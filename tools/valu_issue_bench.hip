@@ -38,6 +38,8 @@ __global__ void __launch_bounds__(1024) issue_kernel(uint64_t *cycles, uint32_t 
     for (int k = 0; k < UNROLL; k++) { a[k] = seed + threadIdx.x * 7 + k; f[k] = (float)(a[k] & 1023) * 1.0e-3f + 1.0f; q[k] = ((uint64_t)a[k] << 20) | k; }
     const float fb = (float)(seed & 7) * 1.0e-7f + 1.0f, fc = (float)(seed & 3) * 1.0e-9f;
     const uint32_t ub = seed | 1u;
+    const uint64_t sel = 0x5555AAAA3333CCCCull ^ seed;       // lane-select mask of the v_cndmask rows, in an SGPR pair (no VCC hazard nops)
+    uint64_t carry = 0;
     __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITER; it++) {
@@ -47,20 +49,20 @@ __global__ void __launch_bounds__(1024) issue_kernel(uint64_t *cycles, uint32_t 
             else if (KIND == K_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(ub));
             else if (KIND == K_MUL24) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[k]) : "v"(ub));
             else if (KIND == K_MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(ub));
-            else if (KIND == K_MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[k]) : "v"(a[k]), "v"(ub) : "vcc");
-            else if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(ub) : "vcc");
+            else if (KIND == K_MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(q[k]), "=s"(carry) : "v"(a[k]), "v"(ub));
+            else if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(ub), "s"(sel));
             else if (KIND == K_RCP_F32) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[k]));
             else if (KIND == K_CVT_F32_I32) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[k]) : "v"(a[k]));
             else if (KIND == K_MIN3_I32) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(ub), "v"(seed));
             else if (KIND == K_PK_FMA_F32) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q[k]) : "v"(q[(k + 1) % UNROLL]));
-            else if (KIND == K_ADD_U64) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, 0, vcc" : "+v"(a[k]), "+v"(a[(k + 4) % UNROLL]) : "v"(ub) : "vcc");
+            else if (KIND == K_ADD_U64) asm volatile("v_add_co_u32 %0, %2, %0, %3\n v_addc_co_u32 %1, %2, %1, 0, %2" : "+v"(a[k]), "+v"(a[(k + 4) % UNROLL]), "=&s"(carry) : "v"(ub));
             else {
                 // eight instructions of the kinds the cull / set-up code is made of
                 switch (k) {
                 case 0: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[0]) : "v"(fb), "v"(fc)); break;
                 case 1: asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[1]) : "v"(ub)); break;
                 case 2: asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[2]) : "v"(ub)); break;
-                case 3: asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[3]) : "v"(ub) : "vcc"); break;
+                case 3: asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[3]) : "v"(ub), "s"(sel)); break;
                 case 4: asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[4]) : "v"(ub), "v"(seed)); break;
                 case 5: asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[5]) : "v"(a[5])); break;
                 case 6: asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[6]) : "v"(ub)); break;
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(1024) issue_kernel(uint64_t *cycles, uint32_t 
     uint32_t acc = 0;
 #pragma unroll
     for (int k = 0; k < UNROLL; k++) acc ^= a[k] ^ __float_as_uint(f[k]) ^ (uint32_t)q[k] ^ (uint32_t)(q[k] >> 32);
-    if (acc == 0x12345678u) sink[0] = acc;                                   // keeps the registers alive
+    if (acc == 0x12345678u) sink[0] = acc ^ (uint32_t)carry;                                   // keeps the registers alive
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -113,11 +115,17 @@ static void sweep(uint64_t *d_cycles, uint32_t *d_sink, std::vector<uint64_t> &h
 {
     printf("  {\"instruction\": \"%s\", \"cycles_per_wave_instruction_per_simd\": {", kind_name[KIND]);
     const int wps[] = {1, 2, 4, 6, 8};
+    double wall[5];
     for (int i = 0; i < 5; i++) {
         double ms;
         const double c = run<KIND>(wps[i], d_cycles, d_sink, h, &ms);
         printf("\"%d\": %.3f%s", wps[i], c, i < 4 ? ", " : "");
+        wall[i] = ms;
     }
+    // the same from the wall clock (HIP events around the launch): ns per wave-instruction per SIMD, launch overhead included
+    printf("}, \"wall_ns_per_wave_instruction_per_simd\": {");
+    for (int i = 0; i < 5; i++)
+        printf("\"%d\": %.3f%s", wps[i], wall[i] * 1.0e6 / ((double)ITER * UNROLL * (KIND == K_ADD_U64 ? 2 : 1) * wps[i]), i < 4 ? ", " : "");
     printf("}}%s\n", last ? "" : ",");
 }
 
