@@ -60,7 +60,8 @@ def test_full_grid_layers_equal_direct_rendering(full):
     cand = helpers.slu_grid(rb.joint_limits, 16)
     for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL):
         _, sums_a, bi_a, _ = e.eval(cand, 6, loss, want_sums=True)
-        for flag in (e.NO_LAYERS, e.NO_PARENTS):                       # no shared layers at all; layers without the second level (per q0)
+        # no shared layers at all; layers without the second level (per q0); one workgroup per (tile, candidate) instead of the queue
+        for flag in (e.NO_LAYERS, e.NO_PARENTS, e.NO_QUEUE, e.NO_LAYERS | e.NO_QUEUE):
             e.set_strategy(flag)
             try:
                 _, sums_b, bi_b, _ = e.eval(cand, 6, loss, want_sums=True)

@@ -24,8 +24,12 @@ NAN = float('nan')
 @pytest.fixture(scope='module')
 def shim(tmp_path_factory):
     out = str(tmp_path_factory.mktemp('shim') / 'libpredict_shim.so')
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-ffp-contract=off', '-fPIC', '-shared',
-                           os.path.join(ROOT, 'rope_s3d_amd', 'csrc', 'rope_predict.cpp'), os.path.join(ROOT, 'tests', 'native_shim.cpp'), '-o', out])
+    # ROPE_SHIM_SANITIZE: the product's host C++ under AddressSanitizer + UBSan (tests/test_host_sanitized.py runs this
+    # module once more in a child process with the sanitiser runtime preloaded)
+    san = ['-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-g'] if os.environ.get('ROPE_SHIM_SANITIZE') else []
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-ffp-contract=off', '-fPIC', '-shared'] + san +
+                          [os.path.join(ROOT, 'rope_s3d_amd', 'csrc', 'rope_predict.cpp'), os.path.join(ROOT, 'rope_s3d_amd', 'csrc', 'rope_meshlets.cpp'),
+                           os.path.join(ROOT, 'tests', 'native_shim.cpp'), '-o', out])
     lib = C.CDLL(out)
     lib.rope_predict.argtypes = [C.c_void_p, C.POINTER(PredictArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.shim_last_error.restype = C.c_char_p
@@ -163,3 +167,34 @@ def test_stage_loop_with_nan_errors_follows_the_reference(shim):
     for k, (kind, ang) in enumerate(trace):
         assert np.array_equal(got_trace[k], ang), (k, kind, got_trace[k], ang)
     assert np.array_equal(out, want)
+
+
+def test_partitioner_and_robot_builder_in_the_host_build(shim):
+    """rope_partition_mesh and rope_set_robot_mesh (csrc/rope_meshlets.cpp) from the same host build as the stage loop: every
+    triangle lands in exactly one patch within the limits, and the arrays handed to rope_set_robot are consistent
+    (the shim's stand-in reads them end to end).  Under ROPE_SHIM_SANITIZE this is the sanitised run of that file."""
+    rb = helpers.robot()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    shim.rope_partition_mesh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for l in range(rb.n_links):
+        V = np.ascontiguousarray(rb.verts[rb.vtx_off[l]:rb.vtx_off[l + 1]], np.float32)
+        F = np.ascontiguousarray(rb.faces[rb.tri_off[l]:rb.tri_off[l + 1]], np.int32)
+        for max_t, max_v in ((128, 64), (32, 24)):
+            order, first = np.empty(len(F), np.int32), np.empty(len(F) + 1, np.int32)
+            m = shim.rope_partition_mesh(p(V), len(V), p(F), len(F), max_t, max_v, p(order), p(first))
+            assert m > 0 and first[0] == 0 and first[m] == len(F) and np.array_equal(np.sort(order), np.arange(len(F)))
+            sizes = np.diff(first[:m + 1])
+            assert sizes.min() >= 1 and sizes.max() <= max_t
+            assert max(len(np.unique(F[order[first[i]:first[i + 1]]])) for i in range(m)) <= max_v
+    shim.rope_set_robot_mesh.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 2
+    shim.shim_last_robot.restype = C.POINTER(C.c_int64)
+    verts, faces = np.ascontiguousarray(rb.verts, np.float32), np.ascontiguousarray(rb.faces, np.int32)
+    vo, to = np.ascontiguousarray(rb.vtx_off, np.int32), np.ascontiguousarray(rb.tri_off, np.int32)
+    jf, ja = np.ascontiguousarray(rb.joint_fixed), np.ascontiguousarray(rb.joint_axes)
+    ctx = C.create_string_buffer(8)                          # any non-null context: the shim's stand-ins never look inside
+    assert shim.rope_set_robot_mesh(ctx, p(verts), p(faces), p(vo), p(to), rb.n_links, p(jf), p(ja)) == 0
+    got = shim.shim_last_robot()
+    assert got[0] == len(rb.meshlets.header) and got[1] == len(rb.meshlets.verts) and got[2] == len(rb.faces)
+    bad = faces.copy()
+    bad[5, 1] = 10 ** 6                                     # an index outside its link: refused, nothing read out of range
+    assert shim.rope_set_robot_mesh(ctx, p(verts), p(bad), p(vo), p(to), rb.n_links, p(jf), p(ja)) == -1
