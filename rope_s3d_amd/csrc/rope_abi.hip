@@ -88,6 +88,10 @@ struct rope_ctx {
     bool gtile_dirty = true;
     int split_target = 6144, split_cap = 32;   // workgroups aimed at per launch / most workgroups per (tile, candidate)
     int strategy = 0;                          // STRATEGY_* bits (rope_set_strategy): launch structure only, never a result
+    // large batches: queue of the (candidate, tile) pairs with something to draw, worked off by a grid that just fills the chip
+    uint32_t *d_qitems = nullptr;
+    int *d_qctr = nullptr;                     // [0] pairs queued, [1] next pair to hand out; cleared by fk_mvp_kernel
+    int n_cu = 256;
 
     // stored lookup table (cropped sqrt-depth of a pose grid)
     float *d_table = nullptr;
@@ -176,6 +180,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
         hipHostMalloc((void **)&c->h_cand, 6 * rope_ctx::HOST_ERR_ROWS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_cand_host, c->h_cand, 0) != hipSuccess ||
         hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void **)&c->d_qctr, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_best_err, sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_PV, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_joint_fixed, 72 * sizeof(double)) != hipSuccess ||
@@ -184,6 +189,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
         delete c;
         return ROPE_E_NOMEM;
     }
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
     *out = c;
     return ROPE_OK;
 }
@@ -221,7 +227,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_zero_total, c->d_tsums, c->d_terr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_qctr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -441,6 +447,7 @@ static int ensure_capacity(rope_ctx *c, int C)
     HIP_TRY(c, realloc_dev(&c->d_mask_hi, (size_t)cap * c->mask_words));
     HIP_TRY(c, realloc_dev(&c->d_layer_of, (size_t)cap));
     HIP_TRY(c, realloc_dev(&c->d_sums, (size_t)cap * ROPE_SUM_WORDS));
+    HIP_TRY(c, realloc_dev(&c->d_qitems, (size_t)cap * c->mask_words * 32));
     c->cap = cap;
     return ROPE_OK;
 }
@@ -610,7 +617,7 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
         return ROPE_OK;
     }
     HIP_TRY(c, launch_fk(c->stream, cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
-                         c->d_mask_lo, c->d_mask_hi, c->mask_words));
+                         c->d_mask_lo, c->d_mask_hi, c->mask_words, c->d_qctr));
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words,
                              n_shared > 0 ? c->d_layer_of : nullptr, n_shared > 0 ? c->d_layer_rep : nullptr));
     return ROPE_OK;
@@ -664,6 +671,9 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->split_target) slices *= 2;
         HIP_TRY(c, launch_score_gtile(loss, c->C, slices, c->stream, fp, a));
         c->gtile_dirty = ROPE_SKIP(fp, ~0);
+    } else if (c->C > 256 && !(c->strategy & STRATEGY_NO_QUEUE)) {
+        // fk_mvp_kernel ran (C > 256) and cleared the queue counters; two 12-wave workgroups fit a CU
+        HIP_TRY(c, launch_raster_queue(loss, c->C, 2 * c->n_cu, c->stream, fp, c->rp, a, c->d_qitems, c->d_qctr));
     } else {
         HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
     }
@@ -1005,7 +1015,7 @@ extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
 extern "C" int rope_set_strategy(rope_ctx *c, int flags)
 {
     if (!c) return ROPE_E_ARG;
-    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
+    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS | STRATEGY_NO_QUEUE)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
     c->strategy = flags;
     return ROPE_OK;
 }

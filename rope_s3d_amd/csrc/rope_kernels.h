@@ -69,7 +69,7 @@ struct FrameParams {
 #endif
 
 // Execution strategies that change the launch structure but never a result (rope_set_strategy)
-enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4 };
+enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4, STRATEGY_NO_QUEUE = 8 };
 
 struct RobotParams {
     const uint32_t *ml_header;            // n_meshlets x 8
@@ -116,7 +116,7 @@ struct RasterArgs {
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
                      const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
-                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words);
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters /* 2 ints cleared for launch_raster_queue, or nullptr */);
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
@@ -129,6 +129,10 @@ hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const Fra
                             uint32_t *mask_hi, int mask_words);
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                          const RasterArgs &a);
+// MODE_SCORE over the (candidate, tile) pairs that have something to draw, from a queue (`items`: rows x tiles entries,
+// `counters`: the two ints launch_fk cleared) by `workgroups` resident workgroups; layer-only tiles are settled on the way
+hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                               const RasterArgs &a, uint32_t *items, int *counters);
 // scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)
 hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a);
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,

@@ -112,10 +112,11 @@ __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
               const double *__restrict__ joint_axes, const double *__restrict__ PV_all, const int32_t *__restrict__ view_of,
               float *__restrict__ mvp, uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi,
-              int mask_words)
+              int mask_words, int *__restrict__ queue_counters)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && queue_counters) queue_counters[0] = queue_counters[1] = 0;      // raster_queue_kernel's, filled later in the pass
     // camera-pose path: every candidate names its own view matrix (camera_pose_prediction.py:116-124)
     const double *__restrict__ PV = PV_all + (view_of ? 16 * (size_t)view_of[c] : 0);
     // first kernel of a pass: clear what the later kernels accumulate into (saves three memset launches)
@@ -655,16 +656,15 @@ __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
 }
 
 
-// MODE_SCORE: reduce the loss and add (actual - empty) into the candidate's sums.
-// MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
-// MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
+// One (screen tile, row) of a raster launch; `row` = candidate, or in MODE_LAYER a shared layer.  zme / zsplit: MODE_SPLIT's
+// share of the tile's meshlets.  Every early return is taken by the whole workgroup.
 template <int LOSS, int MODE>
-__global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
-raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
+__device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotParams &rp, const RasterArgs &ra, const int row,
+                                            const int tile_id, const int zme, const int zsplit)
 {
     const int n_render = ra.n_render;
     // camera-pose path: the candidate (= view x frame) names the frame whose target planes it is scored against
-    const size_t frame = (MODE == MODE_SCORE && ra.frame_of) ? (size_t)ra.frame_of[blockIdx.y] : 0;
+    const size_t frame = (MODE == MODE_SCORE && ra.frame_of) ? (size_t)ra.frame_of[row] : 0;
     const size_t plane = (size_t)fp.W * fp.H;
     const uint64_t *__restrict__ tq = ra.tq ? ra.tq + frame * plane : nullptr;
     const float *__restrict__ t32 = ra.t32 ? ra.t32 + frame * plane : nullptr;
@@ -681,12 +681,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroups go to the 8 XCDs round-robin by linear id, i.e. by (row * n_tiles + blockIdx.x) mod 8: with an even
-    // tile count a given screen tile would only ever meet 4, 2 or 1 of them, and the few tiles that hold the robot
-    // would pile up there.  Rotating the tile index by a per-row hash spreads every tile over all XCDs.
-    const int n_tiles_all = fp.tiles_x * fp.tiles_y;
-    const int tile_id = (int)((blockIdx.x + ((blockIdx.y * 0x9E3779B1u) >> 12)) % (unsigned)n_tiles_all);
-    const int cand = (MODE == MODE_LAYER) ? ra.cand_of_row[blockIdx.y] : (int)blockIdx.y;
+    const int cand = (MODE == MODE_LAYER) ? ra.cand_of_row[row] : row;
     const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
     const int col0 = tx * TILE_W, row0 = ty * TILE_H;
     // tile rectangle in GL window pixel coordinates (y up), clamped to the image
@@ -733,7 +728,6 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     {
         const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
         const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
-        const int zsplit = (MODE == MODE_SPLIT) ? (int)gridDim.z : 1, zme = (MODE == MODE_SPLIT) ? (int)blockIdx.z : 0;
         for (int m = m_begin + tid; m < m_end; m += NTHREADS) {
             if (zsplit > 1 && (m % zsplit) != zme) continue;       // this workgroup's share of the meshlets
             const short4 b = bb[m];
@@ -994,9 +988,9 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     __syncthreads();
 
     if (MODE == MODE_LAYER) {
-        const size_t slot = (size_t)blockIdx.y * (fp.tiles_x * fp.tiles_y) + tile_id;
+        const size_t slot = (size_t)row * (fp.tiles_x * fp.tiles_y) + tile_id;
         // the parent launch skipped the tiles its own candidate's shared links do not touch: nothing to merge there
-        const int prow = ra.base_layers ? ra.base_of_row[blockIdx.y] : 0;
+        const int prow = ra.base_layers ? ra.base_of_row[row] : 0;
         const bool have_base = ra.base_layers && ((ra.mask_lo[(size_t)ra.base_rep[prow] * ra.mask_words + (tile_id >> 5)] >> (tile_id & 31)) & 1u);
         if (have_base) {
             const uint4 *b4 = reinterpret_cast<const uint4 *>(ra.base_layers + ((size_t)prow * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H));
@@ -1059,6 +1053,72 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
         uint64_t delta = lds_sums[tid];
         if (layer_tile) delta += ra.layer_sums[((size_t)ra.layer_of[cand] * (fp.tiles_x * fp.tiles_y) + tile_id) * ROPE_SUM_WORDS + tid];
         if (delta) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid], (unsigned long long)delta);
+    }
+}
+
+// MODE_SCORE: reduce the loss and add (actual - empty) into the candidate's sums.
+// MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
+// MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
+template <int LOSS, int MODE>
+__global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
+raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
+{
+    // Workgroups go to the 8 XCDs round-robin by linear id, i.e. by (row * n_tiles + blockIdx.x) mod 8: with an even
+    // tile count a given screen tile would only ever meet 4, 2 or 1 of them, and the few tiles that hold the robot
+    // would pile up there.  Rotating the tile index by a per-row hash spreads every tile over all XCDs.
+    const int n_tiles_all = fp.tiles_x * fp.tiles_y;
+    const int tile_id = (int)((blockIdx.x + ((blockIdx.y * 0x9E3779B1u) >> 12)) % (unsigned)n_tiles_all);
+    raster_tile<LOSS, MODE>(fp, rp, ra, (int)blockIdx.y, tile_id, (MODE == MODE_SPLIT) ? (int)blockIdx.z : 0, (MODE == MODE_SPLIT) ? (int)gridDim.z : 1);
+}
+
+// Large batches: the (candidate, tile) pairs that have anything to draw, taken from a queue by a grid that just fills the
+// chip (two workgroups per CU) — of the tiles x candidates pairs of a pass about four in five have nothing to do, and a
+// launch over all of them spends a fifth of a millisecond starting workgroups that leave at once.  score_queue_kernel
+// builds the queue.  A workgroup asks for its next pair while it works on the current one.
+template <int LOSS>
+__global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
+raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, int *__restrict__ counters /* [0] pairs queued, [1] next */)
+{
+    __shared__ int s_item;
+    if (threadIdx.x == 0) s_item = atomicAdd(&counters[1], 1);
+    __syncthreads();
+    const int n_items = counters[0];
+    for (;;) {
+        const int item = s_item;
+        if (item >= n_items) break;                        // every wave of the workgroup reads the same value: all leave together
+        __syncthreads();
+        int next = 0;
+        if (threadIdx.x == 0) next = atomicAdd(&counters[1], 1);      // in flight while this pair is drawn
+        const uint32_t it = items[item];
+        raster_tile<LOSS, MODE_SCORE>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);
+        __syncthreads();                                   // the tile's LDS is free again
+        if (threadIdx.x == 0) s_item = next;
+        __syncthreads();
+    }
+}
+
+// The queue of raster_queue_kernel: one workgroup of 32 threads per (candidate, word of its tile masks).  Pairs whose
+// tile the candidate's own links reach (or, without shared layers, any of its links) are queued; where only the shared
+// layer reaches, the candidate takes the layer's stored loss sums here and now.
+__global__ void __launch_bounds__(32)
+score_queue_kernel(RasterArgs ra, int n_tiles, uint32_t *__restrict__ items, int *__restrict__ counters)
+{
+    const int cand = blockIdx.x, w = blockIdx.y, k = threadIdx.x;
+    const uint32_t hi = ra.mask_hi[(size_t)cand * ra.mask_words + w];
+    const bool layers = ra.layer_of != nullptr;
+    const uint32_t lo = ra.mask_lo[(size_t)(layers ? ra.layer_rep[ra.layer_of[cand]] : cand) * ra.mask_words + w];
+    const uint32_t work = layers ? hi : (hi | lo);
+    int base = 0;
+    if (k == 0 && work) base = atomicAdd(&counters[0], __popc(work));
+    base = __shfl(base, 0, 32);
+    if ((work >> k) & 1u) items[base + __popc(work & ((1u << k) - 1u))] = (uint32_t)cand | ((uint32_t)(32 * w + k) << 16);
+    if (layers && k < ROPE_SUM_WORDS) {
+        uint64_t acc = 0;
+        for (uint32_t only = lo & ~hi; only; only &= only - 1) {
+            const int tile = 32 * w + __ffs((int)only) - 1;
+            acc += ra.layer_sums[((size_t)ra.layer_of[cand] * n_tiles + tile) * ROPE_SUM_WORDS + k];
+        }
+        if (acc) atomicAdd((unsigned long long *)&ra.sums[(size_t)cand * ROPE_SUM_WORDS + k], (unsigned long long)acc);
     }
 }
 
@@ -1258,10 +1318,10 @@ static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const R
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
                      const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
-                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words)
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters)
 {
     hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, view_of,
-                       mvp, sums, mask_lo, mask_hi, mask_words);
+                       mvp, sums, mask_lo, mask_hi, mask_words, queue_counters);
     return hipGetLastError();
 }
 
@@ -1304,6 +1364,22 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
     else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a);
     else if (loss == ROPE_LOSS_CAMFULL) launch_one<ROPE_LOSS_CAMFULL, MODE_SCORE>(grid, st, fp, rp, a);
     else launch_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                               const RasterArgs &a, uint32_t *items, int *counters)
+{
+    const int n_tiles = fp.tiles_x * fp.tiles_y;
+    hipLaunchKernelGGL(score_queue_kernel, dim3(rows, a.mask_words), dim3(32), 0, st, a, n_tiles, items, counters);
+    const dim3 grid(workgroups), block(NTHREADS);
+    switch (loss) {
+    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_DEPTH>, grid, block, 0, st, fp, rp, a, items, counters); break;
+    case ROPE_LOSS_FULL: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_FULL>, grid, block, 0, st, fp, rp, a, items, counters); break;
+    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_LOOKUP>, grid, block, 0, st, fp, rp, a, items, counters); break;
+    case ROPE_LOSS_CAMFULL: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_CAMFULL>, grid, block, 0, st, fp, rp, a, items, counters); break;
+    default: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_TSWEEP>, grid, block, 0, st, fp, rp, a, items, counters); break;
+    }
     return hipGetLastError();
 }
 
