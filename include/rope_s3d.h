@@ -188,6 +188,14 @@ typedef struct rope_predict_args {
     int32_t n_lookup;
     int32_t use_table;            /* 1: score the table of rope_lookup_build; 0: render and score the grid now */
     const int32_t *lookup_crop;   /* r0,r1,c0,c1 when use_table == 0 */
+    double *lookup_angles_live;   /* NULL (default): every frame starts from the grid row itself and frames are independent.
+                                     Non-NULL: the reference's table aliasing, opt-in — an n_lookup x 6 copy of the grid that the
+                                     caller keeps from frame to frame.  The Lookup stage takes its row from HERE (scores still
+                                     come from the grid / the stored table), and while the current angles are still that row —
+                                     until an SFlip or a sweep rebinds them — Descent's steps are written back into it, as
+                                     `angles = self.lookup_angles[argmin]` (a numpy view, predict.py:171) followed by
+                                     `angles[idx] += rate` (predict.py:212-215) does in the reference.  Results then depend on
+                                     the order of the frames: one context, frames in sequence. */
 } rope_predict_args;
 
 /*   angles_out  6 doubles

@@ -32,12 +32,19 @@ def _mask(letters):
 
 def predict_reference(o: orc.Oracle, tgt_depth, tgt_blue, link_names, link_blue, joint_limits, camera_pose,
                       lookup_angles, lookup_crop, do_angles='SLU', min_ang_inc=None, stages=None, seg_masks=None,
-                      lookup_depth=None):
+                      lookup_depth=None, lookup_live=None):
     """-> (final angles, trace [(stage kind, angles after it)], number of E(a) evaluations).
 
     Synthetic mode (default): masks are read from `tgt_blue` as _loadSynthetic does.  Segmentation mode:
     pass `seg_masks` {link name: bool mask} and `lookup_depth` as _segmentLoad/_load_target leave them
-    (predict.py:397-442); `tgt_depth` is then the body-masked depth."""
+    (predict.py:397-442); `tgt_depth` is then the body-masked depth.
+
+    `lookup_live`: the reference's cross-frame state, restated literally.  Its run() does
+    `angles = self.lookup_angles[argmin]` — a numpy VIEW of the table row (predict.py:171) — and Descent's
+    `angles[idx] += rate` (predict.py:212-215) then edits the table in place until some stage rebinds `angles`.
+    Pass the same (n, 6) float64 array for every frame of a sequence and this function does exactly that with it
+    (the scores keep coming from `lookup_angles`: the reference's depth table is rendered once from the untouched grid).
+    None: every frame starts from a copy of the grid row."""
     min_ang_inc = np.array([.005] * 6) if min_ang_inc is None else np.asarray(min_ang_inc, float)
     tgt_depth = np.asarray(tgt_depth, np.float64)
     H, W = tgt_depth.shape
@@ -93,9 +100,11 @@ def predict_reference(o: orc.Oracle, tgt_depth, tgt_blue, link_names, link_blue,
                     key = o.raster_key(a, 6)
                     score[i] = o.finalize(o.sums(key, orc.LOSS_LOOKUP, 6, None, t_lookup, crop), orc.LOSS_LOOKUP, 6, npx, flags)
                 count[0] += len(lookup_angles)
-                # copy: the reference keeps a view and later mutates its table in place (a cross-frame state leak
-                # that is deliberately not restated; the first frame of a fresh Predictor is unaffected)
-                angles = np.array(lookup_angles[int(np.argmin(score))], dtype=float)
+                if lookup_live is not None:
+                    assert isinstance(lookup_live, np.ndarray) and lookup_live.dtype == np.float64 and lookup_live.shape == np.shape(lookup_angles)
+                    angles = lookup_live[int(np.argmin(score))]            # a view, as predict.py:171: the stages below edit or rebind it
+                else:
+                    angles = np.array(lookup_angles[int(np.argmin(score))], dtype=float)
 
             elif kind == 'descent':                    # predict.py:173-230
                 _, n, its, letters, init_rate, redux, early = st

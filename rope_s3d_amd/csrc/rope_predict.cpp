@@ -29,6 +29,9 @@ struct State {
     Vec6 lr{{0.1, 0.1, 0.1, 0.1, 0.1, 0.1}};                    // predict.py:144, persists across stages
     double history[HISTORY][6] = {};
     double err_history[HISTORY] = {};
+    // reference table aliasing (rope_predict_args::lookup_angles_live): the row of the live table `angles` still IS —
+    // numpy's view of predict.py:171 — or -1 once a stage has bound the name to another array
+    int alias_row = -1;
 };
 
 struct Machine {
@@ -170,7 +173,9 @@ int stage_lookup(Machine &m, const rope_stage &s, State &st)
         rope_set_error(m.c, "rope_predict: lookup argmin outside the grid (table built for another grid?)");
         return ROPE_E_ARG;
     }
-    for (int j = 0; j < 6; j++) st.angles[j] = m.a.lookup_angles[(size_t)best * 6 + j];
+    const double *table = m.a.lookup_angles_live ? m.a.lookup_angles_live : m.a.lookup_angles;
+    for (int j = 0; j < 6; j++) st.angles[j] = table[(size_t)best * 6 + j];
+    st.alias_row = m.a.lookup_angles_live ? best : -1;
     return ROPE_OK;
 }
 
@@ -250,6 +255,10 @@ int stage_descent(Machine &m, const rope_stage &s, State &st)
         }
         if (settled || stuck) break;
     }
+    // `angles[idx] += rate` edits the array in place (predict.py:212-215): while that array is a row of the live table,
+    // the table keeps the steps
+    if (st.alias_row >= 0)
+        for (int j = 0; j < 6; j++) m.a.lookup_angles_live[(size_t)st.alias_row * 6 + j] = st.angles[j];
     return ROPE_OK;
 }
 
@@ -281,8 +290,9 @@ int stage_sflip(Machine &m, const rope_stage &s, State &st)
         // upper limit's error is used — and an accepted flip IS temp, so its S angle becomes the upper limit regardless
         temp[0] = m.lim(0, 1);
         if (aliased) st.angles = temp;
-        if (m.err.back() < base_err) st.angles = temp;
+        if (m.err.back() < base_err) { st.angles = temp; aliased = true; }
     }
+    if (aliased) st.alias_row = -1;                 // `angles = temp`: the name leaves the table row (temp was a copy)
     return ROPE_OK;
 }
 
@@ -322,8 +332,8 @@ int stage_isweep(Machine &m, const rope_stage &s, State &st)
         const int best_sample = py_argmin(space_err.data(), div);
         const double errs[3] = {base_err, space_err[best_sample], pred_min_err};
         const int min_type = py_argmin(errs, 3);                                // ties go to the earlier entry
-        if (min_type == 1) { st.angles = space[best_sample]; push_front(st.err_history, HISTORY, space_err[best_sample]); }
-        else if (min_type == 2) { st.angles = angs; push_front(st.err_history, HISTORY, pred_min_err); }
+        if (min_type == 1) { st.angles = space[best_sample]; st.alias_row = -1; push_front(st.err_history, HISTORY, space_err[best_sample]); }
+        else if (min_type == 2) { st.angles = angs; st.alias_row = -1; push_front(st.err_history, HISTORY, pred_min_err); }
         push_front(st.history, st.angles);
     }
     return ROPE_OK;

@@ -37,7 +37,8 @@ class PredictArgs(C.Structure):
     """rope_predict_args (include/rope_s3d.h)."""
     _fields_ = [('stages', C.POINTER(StageDesc)), ('n_stages', C.c_int32), ('speculate', C.c_int32),
                 ('limits', C.c_void_p), ('camera_pose', C.c_void_p), ('min_ang_inc', C.c_void_p),
-                ('lookup_angles', C.c_void_p), ('n_lookup', C.c_int32), ('use_table', C.c_int32), ('lookup_crop', C.c_void_p)]
+                ('lookup_angles', C.c_void_p), ('n_lookup', C.c_int32), ('use_table', C.c_int32), ('lookup_crop', C.c_void_p),
+                ('lookup_angles_live', C.c_void_p)]
 
 
 class EngineUnavailable(RuntimeError):
@@ -258,7 +259,7 @@ class Engine:
         return scores, int(bi.value), float(be.value)
 
     def predict(self, stages, limits, camera_pose, min_ang_inc, lookup_angles=None, lookup_crop=None, use_table=False,
-                speculate: int = 3):
+                speculate: int = 3, lookup_live: np.ndarray = None):
         """rope_predict: the whole stage machine of one frame in one call.  `stages` = StageDesc array (or list).
         -> (angles (6,), trace (n_stages, 6), candidate poses evaluated)."""
         arr = stages if isinstance(stages, C.Array) else (StageDesc * len(stages))(*stages)
@@ -267,8 +268,11 @@ class Engine:
         inc = np.ascontiguousarray(min_ang_inc, np.float64).reshape(6)
         grid = np.ascontiguousarray(lookup_angles, np.float64).reshape(-1, 6) if lookup_angles is not None else None
         crop = np.ascontiguousarray(lookup_crop, np.int32).reshape(4) if lookup_crop is not None else None
+        if lookup_live is not None:                  # the reference's table aliasing: edited in place by the library
+            if grid is None or lookup_live.shape != grid.shape or lookup_live.dtype != np.float64 or not lookup_live.flags.c_contiguous:
+                raise ValueError("lookup_live must be a C-contiguous float64 array of the grid's shape")
         a = PredictArgs(arr, len(arr), int(speculate), _p(limits), _p(cam), _p(inc), _p(grid), 0 if grid is None else len(grid),
-                        1 if use_table else 0, _p(crop))
+                        1 if use_table else 0, _p(crop), _p(lookup_live))
         out, trace, n = np.empty(6), np.empty((len(arr), 6)), C.c_int64()
         self._check(self._lib.rope_predict(self._ctx, C.byref(a), _p(out), _p(trace), C.byref(n)), 'rope_predict')
         return out, trace, int(n.value)

@@ -105,7 +105,8 @@ class Predictor:
                  device: int = 0,
                  segmenter: Optional[Callable] = None,
                  lookup_divisions=None,
-                 lookup_table_budget: int = 32 << 30):
+                 lookup_table_budget: int = 32 << 30,
+                 reference_table_aliasing: bool = False):
         """Reference parameters as in predict.py:38-70.  Extra keyword-only arguments:
 
         device            HIP device ordinal of the engine context
@@ -115,6 +116,12 @@ class Predictor:
                           default: the reference's size rule with an 8 GiB budget (simulation/lookup.py)
         lookup_table_budget  bytes of HBM the stored lookup table may take (default 32 GiB); larger grids are
                           rendered and scored on the fly every frame instead
+        reference_table_aliasing  the reference's own behaviour over a SEQUENCE of frames, opt-in: its Lookup stage returns a
+                          numpy view of a row of the angle table (predict.py:171) and Descent then steps that row in place
+                          (predict.py:212-215), so the table drifts and a frame's answer depends on the frames before it
+                          (until the camera pose changes: _loadLookup reloads the table).  Default False: every frame starts
+                          from the grid itself, frames are independent — which is what sharding over GPUs needs.  With True,
+                          use ONE Predictor and feed it the frames in the reference's order.
         """
         self.ds_factor, self.preview = ds_factor, preview
         if preview:                       # headless: frames go to .viz.frame and, with save_to, an uncompressed AVI
@@ -142,6 +149,7 @@ class Predictor:
             self.seg = segmenter if segmenter is not None else self._load_segmenter(model_ds, device)
         self._lookup_divisions = lookup_divisions
         self.lookup_table_budget = int(lookup_table_budget)
+        self.reference_table_aliasing = bool(reference_table_aliasing)
         self.camera_pose = None
         self.changeCameraPose(camera_pose)
         self.evaluations = 0          # candidates rendered+scored, for throughput accounting
@@ -174,6 +182,9 @@ class Predictor:
             div = d
         self.lookup_angles, _ = lm.get(self.crops.size(LOOKUP_NUM_RENDERED), LOOKUP_JOINTS, divisions=div)
         self.lookup_crop = np.asarray(self.crops[LOOKUP_NUM_RENDERED], dtype=np.int32)
+        # reference_table_aliasing: the table the reference's run() edits; the grid itself stays what the depth table
+        # was rendered from (the reference's .h5 depths never change either)
+        self._lookup_live = np.ascontiguousarray(self.lookup_angles, np.float64).copy() if self.reference_table_aliasing else None
         # The reference keeps the grid as a table of cropped depth images (lookup.py:92-106) and takes its square
         # root once (predict.py:117).  Same here, in HBM, when it fits the budget; otherwise every frame renders
         # and scores the grid on the fly (identical scores either way).
@@ -371,7 +382,7 @@ class Predictor:
         native = self._native_stages() if (self.NATIVE and not self.preview) else None
         if native is not None:
             angles, trace, n = self.engine.predict(native, limits, self.camera_pose, self.min_ang_inc, self.lookup_angles,
-                                                   self.lookup_crop, self._lookup_table, self.SPECULATE)
+                                                   self.lookup_crop, self._lookup_table, self.SPECULATE, self._lookup_live)
             self.evaluations += n
             self.trace = [(type(stage).__name__, trace[i].copy()) for i, stage in enumerate(self.stages)]
             return angles
@@ -398,9 +409,12 @@ class Predictor:
         else:
             _, _, best, _ = self.engine.eval(self.lookup_angles, LOOKUP_NUM_RENDERED, LOSS_LOOKUP, crop=self.lookup_crop)
         self.evaluations += len(self.lookup_angles)
-        # .copy(): the reference returns a row VIEW of its angle table (predict.py:171), which the Descent
-        # stage then edits in place (predict.py:213), so its table drifts from frame to frame.  Frames stay
-        # independent here (deliberate deviation); on a fresh Predictor both agree.
+        # The reference returns a row VIEW of its angle table (predict.py:171), which the Descent stage then edits in
+        # place (predict.py:213), so its table drifts from frame to frame.  By default frames stay independent here
+        # (.copy()) — on a fresh Predictor both agree; reference_table_aliasing=True hands out the view of
+        # the live table, and the stages below then behave as the reference's do (in-place steps, rebinding elsewhere).
+        if self._lookup_live is not None:
+            return self._lookup_live[best]
         return self.lookup_angles[best].copy()
 
     def _stage_descent(self, stage, angles, lr, history, err_history, limits):

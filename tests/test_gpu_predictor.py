@@ -459,3 +459,47 @@ def test_predictor_pool_equals_one_predictor(synth):
         assert np.array_equal(pool.run_many(colors, depths, [DEFAULT_CAMERA_POSE] * 10), want)
     assert np.array_equal(pool.run_many(colors[:2], depths[:2]), want[:2]) and pool.run_many([], []).shape == (0, 6)
     assert pool.evaluations > 0 and len(pool) == 3
+
+
+@pytest.mark.parametrize('native', [True, False])
+def test_reference_table_aliasing_over_a_sequence(synth, native):
+    """Predictor(reference_table_aliasing=True): the reference's drifting angle table (predict.py:171,212-215) over five
+    frames of an arm that barely moves — stage by stage against the restatement that lets numpy do the aliasing, with the
+    stage loop in the library and in Python; frame 1 equals the default mode, later frames start from drifted rows."""
+    from rope_s3d_amd import Predictor
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    names = rb.link_names
+    link_blue = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    kw = dict(base_intrin='640_480_color', color_dict=synth.predictor.color_dict, lookup_divisions=4)
+    p = Predictor(DEFAULT_CAMERA_POSE, 4, reference_table_aliasing=True, **kw)
+    p.NATIVE = native
+    q = Predictor(DEFAULT_CAMERA_POSE, 4, **kw)                        # default: independent frames
+    intr, PV = helpers.camera('640_480_color', ds=4, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    grid = helpers.slu_grid(lim, 4)
+    live = grid.copy()
+    rng = np.random.default_rng(31)
+    q0 = np.array([0.30, 0.25, 0.95, 0, 0, 0])
+    differs = 0
+    for f in range(5):
+        q_true = q0 + rng.uniform(-.02, .02, 6) * np.array([1, 1, 1, 0, 0, 0])
+        synth.renderer.setJointAngles(q_true)
+        color, depth = synth.renderer.render()
+        got = np.array(p.run(color, depth))
+        tgt_depth = resize_linear(depth, intr.width, intr.height).astype(np.float64)
+        tgt_blue = resize_linear(color, intr.width, intr.height)[..., 0]
+        want, trace, _ = predictor_ref.predict_reference(o, tgt_depth, tgt_blue, names, link_blue, lim, DEFAULT_CAMERA_POSE, grid, p.lookup_crop,
+                                                         'SLU', lookup_live=live)
+        for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
+            assert np.array_equal(a_ref, a_got), f"frame {f} stage {k_got}: {a_got} vs reference {a_ref}"
+        assert np.array_equal(got, np.array(want)) and np.array_equal(p._lookup_live, live), f
+        ind = q.run(color, depth)
+        if f == 0:
+            assert np.array_equal(ind, got)
+        elif not np.array_equal(q.trace[0][1], p.trace[0][1]):
+            differs += 1
+    assert differs >= 1 and (live != grid).any() and np.array_equal(p.lookup_angles, grid)
+    # a new camera pose reloads the table (changeCameraPose -> _loadLookup, predict.py:105-117)
+    p.changeCameraPose(np.array(DEFAULT_CAMERA_POSE) + [0.01, 0, 0, 0, 0, 0])
+    assert np.array_equal(p._lookup_live, p.lookup_angles)

@@ -198,3 +198,69 @@ def test_partitioner_and_robot_builder_in_the_host_build(shim):
     bad = faces.copy()
     bad[5, 1] = 10 ** 6                                     # an index outside its link: refused, nothing read out of range
     assert shim.rope_set_robot_mesh(ctx, p(verts), p(bad), p(vo), p(to), rb.n_links, p(jf), p(ja)) == -1
+
+
+def test_reference_table_aliasing_over_a_sequence_of_frames(shim):
+    """The reference's Lookup stage hands out a numpy VIEW of its angle table's row (predict.py:171) and Descent steps it in
+    place (predict.py:212-215): over a sequence of frames the table drifts and later frames start from the drifted rows.
+    rope_predict reproduces that when given the live table (lookup_angles_live), decision by decision against the restatement
+    that lets numpy do the aliasing itself — and the default (no live table) keeps frames independent."""
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    pose = DEFAULT_CAMERA_POSE
+    intr, PV = helpers.camera('640_480_color', ds=8, pose=pose, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    grid = helpers.slu_grid(lim, 4)
+    cover = o.coverage(crop_pose_grid(lim, intr.size, 6)[0], 6, threads=THREADS) != 0
+    r, c = np.where(cover)
+    crop = np.array([max(r.min() - 10, 0), min(r.max() + 10, intr.height - 1), max(c.min() - 10, 0), min(c.max() + 10, intr.width - 1)], np.int32)
+    names = rb.link_names
+    blue_of = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    stages = _stages('SLU')
+    arr = (StageDesc * len(stages))(*stages)
+    limits, cam, inc = np.ascontiguousarray(lim, np.float64), np.asarray(pose, np.float64), np.array([.005] * 6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    # five frames of an arm that barely moves: every frame's Lookup lands on the same grid row
+    rng = np.random.default_rng(31)
+    q0 = np.array([0.30, 0.25, 0.95, 0, 0, 0])
+    frames = [q0 + rng.uniform(-.02, .02, 6) * np.array([1, 1, 1, 0, 0, 0]) for _ in range(5)]
+    live_ref, live_nat = grid.copy(), grid.copy()
+    differs_from_independent = 0
+    for f, q_true in enumerate(frames):
+        depth, ids = o.render(q_true, 6)
+        tq, t32, flags, tgt, _, _ = helpers.synthetic_target(depth, ids)
+        blue = np.where(ids == 255, 0, np.asarray(LINK_BLUE)[np.minimum(ids, 5)]).astype(np.uint8)
+
+        @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32))
+        def answer(cand, n, n_render, loss, crop_p, err_out, best_idx):
+            rows = np.ctypeslib.as_array(cand, (n, 6)).copy()
+            if loss == orc.LOSS_LOOKUP:
+                err = o.eval(rows, loss, n_render, tq, t32, np.ctypeslib.as_array(crop_p, (4,)), flags, threads=THREADS)
+            else:
+                err = o.eval(rows, loss, n_render, tq, link_flags=flags, threads=THREADS)
+            if err_out:
+                np.ctypeslib.as_array(err_out, (n,))[:] = err
+            if best_idx:
+                best_idx[0] = int(np.argmin(np.where(np.isnan(err), np.inf, err)))
+            return 0
+        shim.shim_set_callback(answer)
+        want, trace, _ = predictor_ref.predict_reference(o, tgt, blue, names, blue_of, lim, pose, grid, crop, 'SLU', lookup_live=live_ref)
+        want = np.array(want)                                        # the reference returns the view itself; keep this frame's values
+        args = PredictArgs(arr, len(arr), 1 + f % 3, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop), p(live_nat))
+        out, got_trace = np.empty(6), np.empty((len(arr), 6))
+        assert shim.rope_predict(C.c_void_p(1), C.byref(args), p(out), p(got_trace), None) == 0, shim.shim_last_error()
+        for k, (kind, ang) in enumerate(trace):
+            assert np.array_equal(got_trace[k], ang), (f, k, kind, got_trace[k], ang)
+        assert np.array_equal(out, want) and np.array_equal(live_nat, live_ref), f
+        # the same frame on the default path: the grid row itself, whatever came before
+        args = PredictArgs(arr, len(arr), 3, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop), None)
+        ind, ind_trace = np.empty(6), np.empty((len(arr), 6))
+        assert shim.rope_predict(C.c_void_p(1), C.byref(args), p(ind), p(ind_trace), None) == 0
+        assert any(np.array_equal(ind_trace[0], row) for row in grid)
+        if f == 0:
+            assert np.array_equal(ind_trace, got_trace)              # a fresh table: both modes agree on the first frame
+        elif not np.array_equal(ind_trace[0], got_trace[0]):
+            differs_from_independent += 1
+    drifted = np.nonzero((live_ref != grid).any(1))[0]
+    assert len(drifted) >= 1 and differs_from_independent >= 1, (drifted, differs_from_independent)
+    assert np.array_equal(live_ref[:, 3:], grid[:, 3:])               # the joints no Descent stage of 'SLU' touches stay put
