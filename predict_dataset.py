@@ -48,8 +48,16 @@ def run(args):
         from rope_s3d_amd.maskrcnn import BatchAheadSegmenter
         kwargs['segmenter'] = BatchAheadSegmenter(MaskRCNNSegmenter(7, device=f'cuda:{gpu}', state_dict=sd,
                                                                     min_confidence=0.7 if sd is not None else 0.0), batch=8)
+    elif getattr(args, 'segmenter', None) == 'color':
+        # colour-coded frames through the SEGMENTATION path (_segmentLoad: instance merge, dilate 8 / erode 7 body mask) with
+        # exact masks in place of the network's: the whole of configs[2] minus the network's own errors
+        from rope_s3d_amd.segmentation import ColorSegmenter
+        from rope_s3d_amd.urdf import URDFReader
+        kwargs['segmenter'] = ColorSegmenter(['BG'] + list(URDFReader().mesh_names[:6]), ds.attrs.get('color_dict'))
     elif ds.attrs.get('synthetic'):
         kwargs['color_dict'] = ds.attrs['color_dict']         # link masks are read from the colour render
+    if getattr(args, 'lookup_divisions', None):                # default: the reference's size rule (simulation/lookup.py)
+        kwargs['lookup_divisions'] = int(args.lookup_divisions)
     am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
                    do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
     # Frames are independent, and one frame's ~25 short dependent batches leave the GPU idle between them: k Predictors
@@ -95,8 +103,10 @@ if __name__ == "__main__":
     parser.add_argument('dataset', type=str, help="The dataset to predict on.")
     parser.add_argument('-angs', type=str, default='SLU', help="The joints to predict.")
     parser.add_argument('-ds_factor', type=int, default=8, help="Downsampling factor (the reference hard-codes 8).")
-    parser.add_argument('-segmenter', type=str, default=None, choices=[None, 'maskrcnn'],
-                        help="'maskrcnn': segment every frame with the Mask R-CNN stage instead of reading a synthetic set's colours.")
+    parser.add_argument('-segmenter', type=str, default=None, choices=[None, 'maskrcnn', 'color'],
+                        help="'maskrcnn': segment every frame with the Mask R-CNN stage instead of reading a synthetic set's colours; "
+                             "'color': a colour-coded set through the segmentation path with exact masks.")
+    parser.add_argument('-lookup_divisions', type=int, default=None, help="Lookup grid divisions per joint (default: the reference's size rule).")
     parser.add_argument('-predictors', type=int, default=4,
                         help="Predictors (engine contexts + threads) per GPU when the link masks come from the colour render; 1 = one frame at a time.")
     parser.add_argument('-weights', type=str, default=None, help="weights for -segmenter maskrcnn: the reference's trained Keras .h5 or a torch state_dict (random weights otherwise).")

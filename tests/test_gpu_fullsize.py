@@ -326,3 +326,38 @@ def test_full_grid_sample_against_oracle(full):
     err, sums, *_ = e5.eval(cand5, 6, eng.LOSS_DEPTH, want_sums=True)
     err_ref, sums_ref = o5.eval(cand5[pick5], eng.LOSS_DEPTH, 6, tq5, t325, None, fl5, threads=8, want_sums=True)
     assert np.array_equal(sums[pick5], sums_ref) and np.array_equal(err[pick5].view(np.uint64), err_ref.view(np.uint64))
+
+
+def test_cfg5_full_size_grid():
+    """BASELINE configs[4] at its stated size on one GPU: mh50, 1280x720, 32^3 = 32 768 candidates per frame.  All rows:
+    repeatable, equivariant under a permutation of the rows, and the same with nothing shared between candidates and with
+    one workgroup per (tile, candidate); 32 sampled rows against the oracle bit for bit.  (The config's "fp16 depth buffers"
+    have no counterpart: no depth buffer reaches HBM, and the 24-bit window depth in LDS is wider than fp16.)"""
+    rb = helpers.robot('urdfs/motoman_mh50_support/urdf/mh50.urdf')
+    e, intr, PV = make_engine(rb, '1280_720_color', [0, -4.0, 1.5, 0, 0, 0])
+    o = helpers.make_oracle(rb, intr, PV)
+    q_true = np.random.default_rng(7919).uniform(rb.joint_limits[:, 0], rb.joint_limits[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+    d, ids = e.render(q_true, 6)
+    tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+    e.set_target(tq, t32, flags)
+    cand = helpers.slu_grid(rb.joint_limits, 32)
+    assert len(cand) == 32768
+    err, sums, bi, be = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+    assert bi == int(np.nanargmin(err)) and be == err[bi]
+    pick = np.sort(np.random.default_rng(19).choice(len(cand), 32, replace=False))
+    err_ref, sums_ref = o.eval(cand[pick], eng.LOSS_DEPTH, 6, tq, t32, None, flags, threads=16, want_sums=True)
+    assert np.array_equal(sums[pick], sums_ref) and np.array_equal(err[pick].view(np.uint64), err_ref.view(np.uint64))
+    perm = np.random.default_rng(4).permutation(len(cand))
+    err_p, sums_p, bi_p, be_p = e.eval(cand[perm], 6, eng.LOSS_DEPTH, want_sums=True)
+    assert np.array_equal(sums_p, sums[perm]) and np.array_equal(err_p.view(np.uint64), err[perm].view(np.uint64)) and be_p == be
+    for flag in (e.NO_LAYERS, e.NO_QUEUE):
+        e.set_strategy(flag)
+        try:
+            err_b, sums_b, bi_b, _ = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+        finally:
+            e.set_strategy(0)
+        assert np.array_equal(sums_b, sums) and bi_b == bi, flag
+    # the full _error on the same grid: every link term, sampled rows against the oracle
+    err_f, sums_f, *_ = e.eval(cand, 6, eng.LOSS_FULL, want_sums=True)
+    err_ref, sums_ref = o.eval(cand[pick[:12]], eng.LOSS_FULL, 6, tq, t32, None, flags, threads=16, want_sums=True)
+    assert np.array_equal(sums_f[pick[:12]], sums_ref) and np.array_equal(err_f[pick[:12]].view(np.uint64), err_ref.view(np.uint64))
