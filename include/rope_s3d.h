@@ -216,8 +216,10 @@ int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop
  *   1  do not share links 0-2 between candidates with equal (q0, q1): six links drawn per candidate
  *   2  do not split the meshlets of a tile over several workgroups for small batches
  *   4  no second level of sharing (links 0-1 per distinct q0)
- *   8  large batches as one workgroup per (tile, candidate) pair instead of a queue of the pairs that have work */
-enum { ROPE_STRATEGY_NO_LAYERS = 1, ROPE_STRATEGY_NO_SPLIT = 2, ROPE_STRATEGY_NO_PARENTS = 4, ROPE_STRATEGY_NO_QUEUE = 8 };
+ *   8  large batches as one workgroup per (tile, candidate) pair instead of a queue of the pairs that have work
+ *  16  always the raster kernels that can clip triangles at the near plane (by default only when the camera is within the
+ *      robot's reach of it: they are several per cent slower, and without a triangle at the plane they draw the same image) */
+enum { ROPE_STRATEGY_NO_LAYERS = 1, ROPE_STRATEGY_NO_SPLIT = 2, ROPE_STRATEGY_NO_PARENTS = 4, ROPE_STRATEGY_NO_QUEUE = 8, ROPE_STRATEGY_CLIP_KERNELS = 16 };
 int rope_set_strategy(rope_ctx *ctx, int flags);
 
 /* Phase-skipping switches for kernel ablations (rope_debug_skip) exist only in the profiling build of the library

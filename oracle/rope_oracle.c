@@ -140,29 +140,63 @@ void orc_mvp(const double *PV, const double *fk, int n, float *out)
 }
 
 /* --------------------------------------------------------------- raster ---- */
-typedef struct { int32_t X, Y; float d; int ok; } svert;
+/* A shaded vertex.  cls: 0 usable; 1 behind the near plane (z < -w in clip space: its triangle is CLIPPED there, as OpenGL
+ * clips every primitive against the view volume before the viewport transform — pyrender draws through GL, render.py:92-98,
+ * with znear 0.05 m, projection.py:161-169); 2 unusable (beyond the far plane, w <= 0 in front of the near plane, or window
+ * coordinates beyond 1e6 px): its triangles are dropped whole (documented deviation: no far-plane clipping). */
+typedef struct { int32_t X, Y; float d; int cls; float cx, cy, cz, cw; } svert;
+
+/* viewport transform + sub-pixel snap of the clip coordinates already in *o; cls 0 or 2 */
+static inline void to_window(svert *o, float hw, float hh)
+{
+    int ok = (o->cw > 0.0f) && (o->cz <= o->cw);
+    float rw = 1.0f / o->cw;
+    float sx = fmaf(o->cx * rw, hw, hw);
+    float sy = fmaf(o->cy * rw, hh, hh);
+    o->d = fmaf(o->cz * rw, 0.5f, 0.5f);
+    ok = ok && (fabsf(sx) < 1.0e6f) && (fabsf(sy) < 1.0e6f);
+    if (ok) {
+        o->X = (int32_t)rintf(sx * (float)SUBPIX);
+        o->Y = (int32_t)rintf(sy * (float)SUBPIX);
+        o->cls = 0;
+    } else {
+        o->X = o->Y = 0;
+        o->cls = 2;
+    }
+}
 
 static inline svert shade_vertex(const float *m, const float *v, float hw, float hh)
 {
     svert o;
     float x = v[0], y = v[1], z = v[2];
-    float cx = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
-    float cy = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
-    float cz = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11])));
-    float cw = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15])));
-    o.ok = (cw > 0.0f) && (cz >= -cw) && (cz <= cw);
-    float rw = 1.0f / cw;
-    float sx = fmaf(cx * rw, hw, hw);
-    float sy = fmaf(cy * rw, hh, hh);
-    o.d = fmaf(cz * rw, 0.5f, 0.5f);
-    o.ok = o.ok && (fabsf(sx) < 1.0e6f) && (fabsf(sy) < 1.0e6f);
-    if (o.ok) {
-        o.X = (int32_t)rintf(sx * (float)SUBPIX);
-        o.Y = (int32_t)rintf(sy * (float)SUBPIX);
-    } else {
+    o.cx = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
+    o.cy = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
+    o.cz = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11])));
+    o.cw = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15])));
+    if (o.cz < -o.cw) {                              /* behind the near plane (a point behind the eye is, too) */
         o.X = o.Y = 0;
+        o.d = 0.0f;
+        o.cls = 1;
+        return o;
     }
+    to_window(&o, hw, hh);
     return o;
+}
+
+/* Where the edge from `in` (inside: z >= -w) to `out` (behind the near plane) meets that plane, in clip space, then to the
+ * window.  Always evaluated from the inside vertex towards the outside one, so both triangles that share the edge get the
+ * same point bit for bit (no cracks).  One IEEE operation per written step. */
+static inline svert clip_near(const svert *in, const svert *out, float hw, float hh)
+{
+    svert n;
+    float bi = in->cz + in->cw, bo = out->cz + out->cw;
+    float t = bi / (bi - bo);
+    n.cx = fmaf(t, out->cx - in->cx, in->cx);
+    n.cy = fmaf(t, out->cy - in->cy, in->cy);
+    n.cz = fmaf(t, out->cz - in->cz, in->cz);
+    n.cw = fmaf(t, out->cw - in->cw, in->cw);
+    to_window(&n, hw, hh);
+    return n;
 }
 
 static inline int64_t edge_fn(int32_t ax, int32_t ay, int32_t bx, int32_t by, int64_t px, int64_t py)
@@ -181,6 +215,55 @@ static inline int owns(int32_t ax, int32_t ay, int32_t bx, int32_t by)
 static inline int floor_div256(int32_t v) { return v >> 8; }               /* arithmetic shift = floor */
 static inline int ceil_div256(int32_t v) { return -((-v) >> 8); }
 
+/* one triangle of usable window vertices into the key image (back-face cull, top-left rule, GL_LESS on 24-bit depth) */
+static void raster_tri(const svert a, const svert b, const svert c, int l, int W, int H, uint32_t *key)
+{
+    int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
+    if (area2 <= 0) return;                       /* GL_BACK culled, CCW = front */
+    int32_t minX = a.X < b.X ? a.X : b.X; if (c.X < minX) minX = c.X;
+    int32_t maxX = a.X > b.X ? a.X : b.X; if (c.X > maxX) maxX = c.X;
+    int32_t minY = a.Y < b.Y ? a.Y : b.Y; if (c.Y < minY) minY = c.Y;
+    int32_t maxY = a.Y > b.Y ? a.Y : b.Y; if (c.Y > maxY) maxY = c.Y;
+    int x0 = ceil_div256(minX - HALFPIX), x1 = floor_div256(maxX - HALFPIX);
+    int y0 = ceil_div256(minY - HALFPIX), y1 = floor_div256(maxY - HALFPIX);
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > W - 1) x1 = W - 1;
+    if (y1 > H - 1) y1 = H - 1;
+    if (x0 > x1 || y0 > y1) return;
+    int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1;
+    int64_t b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1;
+    int64_t b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
+    /* window-depth plane in float32, anchored at the pixel that holds vertex a */
+    int32_t pxa = a.X >> 8, pya = a.Y >> 8;
+    int64_t fxa = (int64_t)pxa * SUBPIX + HALFPIX, fya = (int64_t)pya * SUBPIX + HALFPIX;
+    int64_t E20a = edge_fn(c.X, c.Y, a.X, a.Y, fxa, fya), E01a = edge_fn(a.X, a.Y, b.X, b.Y, fxa, fya);
+    float inv = 1.0f / (float)(double)area2;
+    float e1 = b.d - a.d, e2 = c.d - a.d;
+    float fA20 = (float)(-(a.Y - c.Y)), fB20 = (float)(a.X - c.X);
+    float fA01 = (float)(-(b.Y - a.Y)), fB01 = (float)(b.X - a.X);
+    float gx = (((e1 * fA20) + (e2 * fA01)) * inv) * 256.0f;
+    float gy = (((e1 * fB20) + (e2 * fB01)) * inv) * 256.0f;
+    float dc = a.d + (((e1 * (float)(double)E20a) + (e2 * (float)(double)E01a)) * inv);
+    for (int py = y0; py <= y1; py++) {
+        int64_t fy = (int64_t)py * SUBPIX + HALFPIX;
+        for (int px = x0; px <= x1; px++) {
+            int64_t fx = (int64_t)px * SUBPIX + HALFPIX;
+            int64_t E01 = edge_fn(a.X, a.Y, b.X, b.Y, fx, fy);
+            int64_t E12 = edge_fn(b.X, b.Y, c.X, c.Y, fx, fy);
+            int64_t E20 = edge_fn(c.X, c.Y, a.X, a.Y, fx, fy);
+            if ((E01 + b01) < 0 || (E12 + b12) < 0 || (E20 + b20) < 0) continue;
+            float d = fmaf(gx, (float)(px - pxa), fmaf(gy, (float)(py - pya), dc));
+            float qf = rintf(d * 16777215.0f);
+            uint32_t d24 = !(qf >= 0.0f) ? 0u : (qf >= 16777215.0f ? D24_MAX : (uint32_t)qf);
+            if (d24 >= D24_MAX) continue;            /* GL_LESS against the cleared 1.0 */
+            uint32_t k = (d24 << 8) | (uint32_t)l;
+            uint32_t *dst = key + (size_t)(H - 1 - py) * W + px;
+            if (k < *dst) *dst = k;
+        }
+    }
+}
+
 /* Rasterise `n_links` links into key image `key` (H x W, row 0 = top of the image).
  * key = (d24 << 8) | link_id, KEY_EMPTY where nothing was drawn. */
 void orc_raster(const float *verts, const int32_t *faces, const int32_t *vtx_off, const int32_t *tri_off,
@@ -194,51 +277,25 @@ void orc_raster(const float *verts, const int32_t *faces, const int32_t *vtx_off
         const float *m = mvp + 16 * l;
         for (int i = 0; i < nv; i++) sv[i] = shade_vertex(m, verts + 3 * (size_t)(vtx_off[l] + i), hw, hh);
         for (int t = tri_off[l]; t < tri_off[l + 1]; t++) {
-            const svert a = sv[faces[3 * t]], b = sv[faces[3 * t + 1]], c = sv[faces[3 * t + 2]];
-            if (!(a.ok && b.ok && c.ok)) continue;
-            int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
-            if (area2 <= 0) continue;                     /* GL_BACK culled, CCW = front */
-            int32_t minX = a.X < b.X ? a.X : b.X; if (c.X < minX) minX = c.X;
-            int32_t maxX = a.X > b.X ? a.X : b.X; if (c.X > maxX) maxX = c.X;
-            int32_t minY = a.Y < b.Y ? a.Y : b.Y; if (c.Y < minY) minY = c.Y;
-            int32_t maxY = a.Y > b.Y ? a.Y : b.Y; if (c.Y > maxY) maxY = c.Y;
-            int x0 = ceil_div256(minX - HALFPIX), x1 = floor_div256(maxX - HALFPIX);
-            int y0 = ceil_div256(minY - HALFPIX), y1 = floor_div256(maxY - HALFPIX);
-            if (x0 < 0) x0 = 0;
-            if (y0 < 0) y0 = 0;
-            if (x1 > W - 1) x1 = W - 1;
-            if (y1 > H - 1) y1 = H - 1;
-            if (x0 > x1 || y0 > y1) continue;
-            int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1;
-            int64_t b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1;
-            int64_t b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
-            /* window-depth plane in float32, anchored at the pixel that holds vertex a */
-            int32_t pxa = a.X >> 8, pya = a.Y >> 8;
-            int64_t fxa = (int64_t)pxa * SUBPIX + HALFPIX, fya = (int64_t)pya * SUBPIX + HALFPIX;
-            int64_t E20a = edge_fn(c.X, c.Y, a.X, a.Y, fxa, fya), E01a = edge_fn(a.X, a.Y, b.X, b.Y, fxa, fya);
-            float inv = 1.0f / (float)(double)area2;
-            float e1 = b.d - a.d, e2 = c.d - a.d;
-            float fA20 = (float)(-(a.Y - c.Y)), fB20 = (float)(a.X - c.X);
-            float fA01 = (float)(-(b.Y - a.Y)), fB01 = (float)(b.X - a.X);
-            float gx = (((e1 * fA20) + (e2 * fA01)) * inv) * 256.0f;
-            float gy = (((e1 * fB20) + (e2 * fB01)) * inv) * 256.0f;
-            float dc = a.d + (((e1 * (float)(double)E20a) + (e2 * (float)(double)E01a)) * inv);
-            for (int py = y0; py <= y1; py++) {
-                int64_t fy = (int64_t)py * SUBPIX + HALFPIX;
-                for (int px = x0; px <= x1; px++) {
-                    int64_t fx = (int64_t)px * SUBPIX + HALFPIX;
-                    int64_t E01 = edge_fn(a.X, a.Y, b.X, b.Y, fx, fy);
-                    int64_t E12 = edge_fn(b.X, b.Y, c.X, c.Y, fx, fy);
-                    int64_t E20 = edge_fn(c.X, c.Y, a.X, a.Y, fx, fy);
-                    if ((E01 + b01) < 0 || (E12 + b12) < 0 || (E20 + b20) < 0) continue;
-                    float d = fmaf(gx, (float)(px - pxa), fmaf(gy, (float)(py - pya), dc));
-                    float qf = rintf(d * 16777215.0f);
-                    uint32_t d24 = !(qf >= 0.0f) ? 0u : (qf >= 16777215.0f ? D24_MAX : (uint32_t)qf);
-                    if (d24 >= D24_MAX) continue;            /* GL_LESS against the cleared 1.0 */
-                    uint32_t k = (d24 << 8) | (uint32_t)l;
-                    uint32_t *dst = key + (size_t)(H - 1 - py) * W + px;
-                    if (k < *dst) *dst = k;
-                }
+            svert v[3] = {sv[faces[3 * t]], sv[faces[3 * t + 1]], sv[faces[3 * t + 2]]};
+            if (v[0].cls == 2 || v[1].cls == 2 || v[2].cls == 2) continue;
+            const int n_near = (v[0].cls == 1) + (v[1].cls == 1) + (v[2].cls == 1);
+            if (n_near == 0) { raster_tri(v[0], v[1], v[2], l, W, H, key); continue; }
+            if (n_near == 3) continue;
+            /* near-plane clipping: rotate the vertex order (the winding stays) so that the odd one out comes first */
+            const int odd = n_near == 1 ? (v[0].cls == 1 ? 0 : (v[1].cls == 1 ? 1 : 2)) : (v[0].cls == 0 ? 0 : (v[1].cls == 0 ? 1 : 2));
+            const svert p = v[odd], q = v[(odd + 1) % 3], r = v[(odd + 2) % 3];
+            if (n_near == 1) {
+                /* p is cut off: the quad A q r B with A on p-q and B on r-p, as two triangles */
+                const svert A = clip_near(&q, &p, hw, hh), B = clip_near(&r, &p, hw, hh);
+                if (A.cls || B.cls) continue;
+                raster_tri(A, q, r, l, W, H, key);
+                raster_tri(A, r, B, l, W, H, key);
+            } else {
+                /* only p is in front: the triangle p A B with A on p-q and B on p-r */
+                const svert A = clip_near(&p, &q, hw, hh), B = clip_near(&p, &r, hw, hh);
+                if (A.cls || B.cls) continue;
+                raster_tri(p, A, B, l, W, H, key);
             }
         }
         free(sv);

@@ -26,6 +26,9 @@ struct rope_ctx {
     float *d_verts = nullptr, *d_aabb = nullptr;
     double *d_joint_fixed = nullptr, *d_joint_axes = nullptr;
     int n_links = 0, n_meshlets = 0;
+    double reach = 0.0;                     // no point of any link, at any joint angles, is farther than this from the base frame's origin
+    double h_PV[16] = {};                   // host copy of the camera matrix (the near-plane test below)
+    bool clip_views = false;                // rope_eval_views: one of the call's cameras is close enough for near-plane clipping
 
     // camera
     bool have_camera = false;
@@ -287,6 +290,23 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
             }
         }
     }
+    // how far from the base origin a vertex can get: joints rotate, so a link's points stay within the sum of the joint
+    // offsets up to it plus the link's own extent about its origin — whatever the joint angles
+    double reach = 0.0, chain = 0.0;
+    for (int l = 0; l < n_links; l++) {
+        if (l > 0) chain += std::sqrt(joint_fixed[12 * (l - 1) + 3] * joint_fixed[12 * (l - 1) + 3] + joint_fixed[12 * (l - 1) + 7] * joint_fixed[12 * (l - 1) + 7] +
+                                      joint_fixed[12 * (l - 1) + 11] * joint_fixed[12 * (l - 1) + 11]);
+        double r = 0.0;
+        for (int m = link_first[l]; m < link_first[l + 1]; m++) {
+            double far2 = 0.0;
+            for (int k = 0; k < 3; k++) {
+                const double a = std::fabs((double)aabb[8 * (size_t)m + k]) + (double)aabb[8 * (size_t)m + 4 + k];
+                far2 += a * a;
+            }
+            r = std::max(r, std::sqrt(far2));
+        }
+        reach = std::max(reach, chain + r);
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, realloc_dev(&c->d_header, 8 * (size_t)n_meshlets));
@@ -310,6 +330,7 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
     c->table_C = 0;
     c->n_links = n_links;
     c->n_meshlets = n_meshlets;
+    c->reach = reach;
     c->have_robot = true;
     return ROPE_OK;
 }
@@ -348,6 +369,7 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
         }
     }
     HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
+    std::memcpy(c->h_PV, PV, sizeof c->h_PV);
     c->fp.W = W; c->fp.H = H;
     c->fp.tiles_x = tiles_x;
     c->fp.tiles_y = tiles_y;
@@ -429,6 +451,24 @@ extern "C" int rope_downsample_even(const void *src, int H, int W, int channels,
             }
     }
     return ROPE_OK;
+}
+
+// Can a vertex of the robot get behind the near plane of camera PV (P·V, row-major doubles)?  z + w is affine in the world
+// position; over the ball of radius `reach` about the base origin it is at least its value at the origin minus |gradient|
+// times the radius.  Conservative with a centimetre to spare: "no" means the kernels without the clipping code draw every
+// triangle exactly as the clipping ones would.
+static bool near_plane_in_reach(const rope_ctx *c, const double *PV)
+{
+    const double g[3] = {PV[8] + PV[12], PV[9] + PV[13], PV[10] + PV[14]}, h = PV[11] + PV[15];
+    const double gn = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    return !(h - gn * (c->reach + 0.01) > 0.0);                  // NaN counts as "in reach"
+}
+
+// the raster kernels that can clip, for this context's camera (or, on the camera-pose path, the current call's cameras)
+static bool use_clip(const rope_ctx *c, bool views = false)
+{
+    if (c->strategy & STRATEGY_CLIP_KERNELS) return true;
+    return views ? c->clip_views : near_plane_in_reach(c, c->h_PV);
 }
 
 static int ensure_capacity(rope_ctx *c, int C)
@@ -588,12 +628,12 @@ static int enqueue_layers(rope_ctx *c, RasterArgs la, int loss, int n_shared, co
         }
         RasterArgs pa = la;
         pa.l_begin = 0; pa.l_end = 2; pa.cand_of_row = c->d_parent_rep; pa.layers = c->d_parents; pa.layer_sums = nullptr;
-        HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_parents, c->stream, fp, c->rp, pa));
+        HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_parents, c->stream, fp, c->rp, pa, use_clip(c)));
         la.l_begin = 2; la.l_end = 3; la.base_layers = c->d_parents; la.base_of_row = c->d_parent_of; la.base_rep = c->d_parent_rep;
     } else {
         la.l_begin = 0; la.l_end = n_shared;
     }
-    HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la));
+    HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la, use_clip(c)));
     return ROPE_OK;
 }
 
@@ -654,7 +694,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         c->gtile_dirty = true;
         RasterArgs sa = a;
         sa.split = split; sa.gtile = c->d_gtile;
-        HIP_TRY(c, launch_raster(MODE_SPLIT, loss, c->C, c->stream, fp, c->rp, sa));
+        HIP_TRY(c, launch_raster(MODE_SPLIT, loss, c->C, c->stream, fp, c->rp, sa, use_clip(c, views)));
         a.gtile = c->d_gtile;
     }
     if (layers) {
@@ -673,9 +713,9 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         c->gtile_dirty = ROPE_SKIP(fp, ~0);
     } else if (c->C > 256 && !(c->strategy & STRATEGY_NO_QUEUE)) {
         // fk_mvp_kernel ran (C > 256) and cleared the queue counters; two 12-wave workgroups fit a CU
-        HIP_TRY(c, launch_raster_queue(loss, c->C, 2 * c->n_cu, c->stream, fp, c->rp, a, c->d_qitems, c->d_qctr));
+        HIP_TRY(c, launch_raster_queue(loss, c->C, 2 * c->n_cu, c->stream, fp, c->rp, a, c->d_qitems, c->d_qctr, use_clip(c, views)));
     } else {
-        HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a));
+        HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a, use_clip(c, views)));
     }
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
@@ -770,7 +810,7 @@ static int raster_only(rope_ctx *c, const double *cand, int C, int n_render, int
     if (rc) return rc;
     RasterArgs a = base_args(c, n_render);
     a.key_out = c->d_key; a.cover = c->d_cover;
-    HIP_TRY(c, launch_raster(mode, ROPE_LOSS_DEPTH, c->C, c->stream, c->fp, c->rp, a));
+    HIP_TRY(c, launch_raster(mode, ROPE_LOSS_DEPTH, c->C, c->stream, c->fp, c->rp, a, use_clip(c)));
     c->last_n_render = n_render;
     return ROPE_OK;
 }
@@ -854,7 +894,7 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
             a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers;
         }
         a.table = c->d_table + (size_t)lo * px;
-        HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a));
+        HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a, use_clip(c)));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->table_C = C;
@@ -932,6 +972,8 @@ extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_rende
     for (size_t i = 0; i < 16 * (size_t)K; i++)
         if (!std::isfinite(PV[i])) ARG_FAIL(c, "rope_eval_views: non-finite view matrix");
     HIP_TRY(c, hipSetDevice(c->device));
+    c->clip_views = false;
+    for (int k = 0; k < K; k++) c->clip_views = c->clip_views || near_plane_in_reach(c, PV + 16 * (size_t)k);
     const int N = c->n_frames, C = K * N;
     int rc = ensure_capacity(c, C);
     if (rc) return rc;
@@ -1015,7 +1057,7 @@ extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
 extern "C" int rope_set_strategy(rope_ctx *c, int flags)
 {
     if (!c) return ROPE_E_ARG;
-    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS | STRATEGY_NO_QUEUE)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
+    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS | STRATEGY_NO_QUEUE | STRATEGY_CLIP_KERNELS)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
     c->strategy = flags;
     return ROPE_OK;
 }

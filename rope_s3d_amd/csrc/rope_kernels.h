@@ -69,7 +69,7 @@ struct FrameParams {
 #endif
 
 // Execution strategies that change the launch structure but never a result (rope_set_strategy)
-enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4, STRATEGY_NO_QUEUE = 8 };
+enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4, STRATEGY_NO_QUEUE = 8, STRATEGY_CLIP_KERNELS = 16 };
 
 struct RobotParams {
     const uint32_t *ml_header;            // n_meshlets x 8
@@ -127,12 +127,14 @@ hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const Fra
                             int n_shared, const double *joint_fixed, const double *joint_axes, const double *PV,
                             const int32_t *view_of, float *mvp, short4 *bounds, uint64_t *sums, uint32_t *mask_lo,
                             uint32_t *mask_hi, int mask_words);
+// clip: the kernels that can cut triangles at the near plane (slower by several per cent: only when the camera is close
+// enough to the robot for a triangle to reach the plane)
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                         const RasterArgs &a);
+                         const RasterArgs &a, bool clip);
 // MODE_SCORE over the (candidate, tile) pairs that have something to draw, from a queue (`items`: rows x tiles entries,
 // `counters`: the two ints launch_fk cleared) by `workgroups` resident workgroups; layer-only tiles are settled on the way
 hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                               const RasterArgs &a, uint32_t *items, int *counters);
+                               const RasterArgs &a, uint32_t *items, int *counters, bool clip);
 // scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)
 hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a);
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,

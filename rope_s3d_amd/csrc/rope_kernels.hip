@@ -405,6 +405,49 @@ __device__ static inline SVert shade_vertex(const float *m, float x, float y, fl
     return o;
 }
 
+// ---- near-plane clipping (the rare path: a meshlet that reaches the near plane).  OpenGL clips every primitive against the
+// view volume before the viewport transform; pyrender draws through GL (render.py:92-98) with znear 0.05 m
+// (projection.py:161-169).  Same operations in the same order as oracle/rope_oracle.c (to_window, clip_near).
+struct ClipVert { float cx, cy, cz, cw; };
+
+__device__ static inline ClipVert clip_coords(const float *m, float x, float y, float z)
+{
+    ClipVert v;
+    v.cx = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
+    v.cy = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
+    v.cz = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11])));
+    v.cw = fmaf(m[12], x, fmaf(m[13], y, fmaf(m[14], z, m[15])));
+    return v;
+}
+
+// viewport transform + sub-pixel snap; false: unusable (beyond the far plane, w <= 0, or off by more than 1e6 px)
+__device__ static inline bool to_window(const ClipVert &v, float hw, float hh, SVert &o)
+{
+    bool ok = (v.cw > 0.0f) && (v.cz <= v.cw);
+    const float rw = 1.0f / v.cw;
+    const float sx = fmaf(v.cx * rw, hw, hw);
+    const float sy = fmaf(v.cy * rw, hh, hh);
+    o.d = fmaf(v.cz * rw, 0.5f, 0.5f);
+    ok = ok && (fabsf(sx) < 1.0e6f) && (fabsf(sy) < 1.0e6f);
+    o.X = ok ? (int32_t)rintf(sx * 256.0f) : SV_BAD;
+    o.Y = ok ? (int32_t)rintf(sy * 256.0f) : 0;
+    return ok;
+}
+
+// where the edge from `in` (z >= -w) to `out` (behind the near plane) meets the plane; always from the inside vertex, so
+// the two triangles that share the edge get the same point
+__device__ static inline ClipVert clip_near(const ClipVert &in, const ClipVert &out)
+{
+    const float bi = in.cz + in.cw, bo = out.cz + out.cw;
+    const float t = bi / (bi - bo);
+    ClipVert n;
+    n.cx = fmaf(t, out.cx - in.cx, in.cx);
+    n.cy = fmaf(t, out.cy - in.cy, in.cy);
+    n.cz = fmaf(t, out.cz - in.cz, in.cz);
+    n.cw = fmaf(t, out.cw - in.cw, in.cw);
+    return n;
+}
+
 __device__ static inline bool owns(int32_t ax, int32_t ay, int32_t bx, int32_t by)
 {
     int32_t dy = by - ay, dx = bx - ax;
@@ -432,14 +475,18 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
     const float *mm = mvp6 + l * 16;
     const float hw = 0.5f * (float)fp.W, hh = 0.5f * (float)fp.H;
     float sxlo = 3.0e38f, sxhi = -3.0e38f, sylo = 3.0e38f, syhi = -3.0e38f;
-    bool behind = false, front = false;
+    bool behind = false, front = false, near = false;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const float x = ctr.x + ((k & 1) ? ext.x : -ext.x), y = ctr.y + ((k & 2) ? ext.y : -ext.y),
                     z = ctr.z + ((k & 4) ? ext.z : -ext.z);
         const float cx = fmaf(mm[0], x, fmaf(mm[1], y, fmaf(mm[2], z, mm[3])));
         const float cy = fmaf(mm[4], x, fmaf(mm[5], y, fmaf(mm[6], z, mm[7])));
+        const float cz = fmaf(mm[8], x, fmaf(mm[9], y, fmaf(mm[10], z, mm[11])));
         const float cw = fmaf(mm[12], x, fmaf(mm[13], y, fmaf(mm[14], z, mm[15])));
+        // z + w is affine in the position, so its smallest value over the box is at a corner: a meshlet none of whose
+        // corners comes within a millimetre of the near plane has no vertex behind it (margin over the rounding of both)
+        if (cz + cw < fmaf(1.0e-5f, fabsf(cw), 1.0e-3f)) near = true;
         if (cw <= 1e-4f) { behind = true; continue; }
         front = true;
         const float rw = 1.0f / cw;
@@ -449,7 +496,9 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
     }
     if (!front) return bb;
     int x0, x1, y0, y1;
-    if (behind) { x0 = 0; x1 = fp.W - 1; y0 = 0; y1 = fp.H - 1; }   // straddles the eye plane: cannot bound
+    // straddles the eye plane: cannot bound; reaches the near plane: its triangles are clipped there and the pieces may lie
+    // anywhere inside the projection of what is in front — not bounded either (rare: a camera within centimetres)
+    if (behind || near) { x0 = 0; x1 = fp.W - 1; y0 = 0; y1 = fp.H - 1; }
     else {
         // sample centre p+0.5 inside [lo,hi] (+ margin)  <=>  p in [lo-1.5, hi+0.5]
         x0 = (int)fmaxf(floorf(sxlo - 1.5f), 0.0f); x1 = (int)fminf(ceilf(sxhi + 0.5f), (float)(fp.W - 1));
@@ -457,8 +506,9 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
     }
     if (x0 > x1 || y0 > y1) return bb;
     // bit 14 of x0: the meshlet's unclamped screen extent is at most COMPACT_PX both ways
-    const bool compact = !behind && (sxhi - sxlo) <= (float)COMPACT_PX && (syhi - sylo) <= (float)COMPACT_PX;
-    bb = make_short4((short)(x0 | (compact ? 0x4000 : 0)), (short)x1, (short)y0, (short)y1);
+    // bit 13 of x0 (images are at most 8192 wide): the meshlet reaches the near plane and takes the clipping path
+    const bool compact = !behind && !near && (sxhi - sxlo) <= (float)COMPACT_PX && (syhi - sylo) <= (float)COMPACT_PX;
+    bb = make_short4((short)(x0 | (compact ? 0x4000 : 0) | (near ? 0x2000 : 0)), (short)x1, (short)y0, (short)y1);
     const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
     const int ty0 = (fp.H - 1 - y1) / TILE_H, ty1 = (fp.H - 1 - y0) / TILE_H;
     for (int ty = ty0; ty <= ty1; ty++)
@@ -626,6 +676,75 @@ __device__ static inline void depth_test_write(uint32_t *tile, int u, int v, con
         atomicMin(&tile[(TILE_H - 1 - v) * TILE_W + u], (d24 << 8) | link);
 }
 
+// One triangle of window vertices into the tile, sample by sample in 64-bit arithmetic by ONE lane: the exact form the
+// fast paths are algebraically equal to.  Used where speed does not matter: triangles with edges beyond 16384 px, and
+// the pieces of triangles clipped at the near plane.  [wx0, wx1] x [wy0, wy1]: the tile in window pixels.
+__device__ __forceinline__ void raster_exact(uint32_t *tile, const SVert &a, const SVert &b, const SVert &c, uint32_t l, const TileFrame &tf,
+                                           int wx0, int wx1, int wy0, int wy1)
+{
+    const int64_t area2 = (int64_t)(b.X - a.X) * (int64_t)(c.Y - a.Y) - (int64_t)(c.X - a.X) * (int64_t)(b.Y - a.Y);
+    if (area2 <= 0) return;                                   // GL_BACK culled, CCW = front
+    const int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
+    const int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
+    const int x0 = max(-((-(minX - 128)) >> 8), wx0), x1 = min((maxX - 128) >> 8, wx1);
+    const int y0 = max(-((-(minY - 128)) >> 8), wy0), y1 = min((maxY - 128) >> 8, wy1);
+    if (x0 > x1 || y0 > y1) return;
+    const Plane pl = make_plane(a, b, c, area2);
+    const int32_t pxa = a.X >> 8, pya = a.Y >> 8;
+    const int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1, b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1, b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
+    for (int py = y0; py <= y1; py++)
+        for (int px = x0; px <= x1; px++) {
+            const int32_t fx = px * 256 + 128, fy = py * 256 + 128;
+            if (((edge_fn(a.X, a.Y, b.X, b.Y, fx, fy) + b01) | (edge_fn(b.X, b.Y, c.X, c.Y, fx, fy) + b12) |
+                 (edge_fn(c.X, c.Y, a.X, a.Y, fx, fy) + b20)) < 0) continue;
+            depth_test_write(tile, px - tf.col0, py - tf.vy0, pl, (float)(px - pxa), (float)(py - pya), l);
+        }
+}
+
+// A meshlet that reaches the near plane: one triangle per lane, from the link-frame vertices, cut at the plane where it
+// crosses it, and every piece drawn by raster_exact.  Slow and rare — a camera within centimetres of the robot; the
+// meshlets that stay in front of the plane never come here.  Called in a pass of its own after the tile's other meshlets
+// (inside their loop its register needs cost the hot path 4 %: measured).
+__device__ __forceinline__ void clipped_meshlet(uint32_t *tile, const float *mm, const float *verts, const uint32_t *tris, int nt,
+                                                                 uint32_t l, float hw, float hh, const TileFrame tf, int wx0, int wx1, int wy0, int wy1)
+{
+    for (int t = (int)(threadIdx.x & 63); t < nt; t += 64) {
+        const uint32_t packed = tris[t];
+        const float *p0 = verts + 3 * (size_t)(packed & 0xFF), *p1 = verts + 3 * (size_t)((packed >> 8) & 0xFF), *p2 = verts + 3 * (size_t)((packed >> 16) & 0xFF);
+        const ClipVert c0 = clip_coords(mm, p0[0], p0[1], p0[2]), c1 = clip_coords(mm, p1[0], p1[1], p1[2]), c2 = clip_coords(mm, p2[0], p2[1], p2[2]);
+        const bool n0 = c0.cz < -c0.cw, n1 = c1.cz < -c1.cw, n2 = c2.cz < -c2.cw;       // behind the near plane
+        const int n_near = (int)n0 + (int)n1 + (int)n2;
+        if (n_near == 3) continue;
+        SVert s0 = {SV_BAD, 0, 0.0f}, s1 = s0, s2 = s0;
+        // a vertex in front of the plane that has no window position (beyond the far plane, ...) drops the triangle
+        if ((!n0 && !to_window(c0, hw, hh, s0)) || (!n1 && !to_window(c1, hw, hh, s1)) || (!n2 && !to_window(c2, hw, hh, s2))) continue;
+        // up to two triangles come out; they are drawn by ONE call below (a single inlined copy of the sample loop)
+        SVert ta = s0, tb = s1, tc = s2, ua = s0, ub = s0, uc = s0;
+        int n_out = 1;
+        if (n_near != 0) {
+            // rotate the vertex order (the winding stays) so that the odd one out comes first
+            const int odd = n_near == 1 ? (n0 ? 0 : (n1 ? 1 : 2)) : (!n0 ? 0 : (!n1 ? 1 : 2));
+            const ClipVert cp = odd == 0 ? c0 : (odd == 1 ? c1 : c2), cq = odd == 0 ? c1 : (odd == 1 ? c2 : c0), cr = odd == 0 ? c2 : (odd == 1 ? c0 : c1);
+            const SVert sp = odd == 0 ? s0 : (odd == 1 ? s1 : s2), sq = odd == 0 ? s1 : (odd == 1 ? s2 : s0), sr = odd == 0 ? s2 : (odd == 1 ? s0 : s1);
+            SVert A, B;
+            if (n_near == 1) {
+                // p is cut off: the quad A q r B with A on p-q and B on r-p, as the triangles (A, q, r) and (A, r, B)
+                if (!to_window(clip_near(cq, cp), hw, hh, A) || !to_window(clip_near(cr, cp), hw, hh, B)) continue;
+                ta = A; tb = sq; tc = sr;
+                ua = A; ub = sr; uc = B;
+                n_out = 2;
+            } else {
+                // only p is in front: the triangle p A B with A on p-q and B on p-r
+                if (!to_window(clip_near(cp, cq), hw, hh, A) || !to_window(clip_near(cp, cr), hw, hh, B)) continue;
+                ta = sp; tb = A; tc = B;
+            }
+        }
+        for (int k = 0; k < n_out; k++) {
+            raster_exact(tile, k ? ua : ta, k ? ub : tb, k ? uc : tc, l, tf, wx0, wx1, wy0, wy1);
+        }
+    }
+}
+
 // largest u with A*u <= n (A > 0): float estimate, then exact fix-up by one either way; clamped to [-4, TILE_W+3]
 __device__ static inline int floor_div_pos(int32_t n, int32_t A, float rcpA)
 {
@@ -657,8 +776,11 @@ __device__ static inline void clip_span(const Edge &e, int v, int &lo, int &hi)
 
 
 // One (screen tile, row) of a raster launch; `row` = candidate, or in MODE_LAYER a shared layer.  zme / zsplit: MODE_SPLIT's
-// share of the tile's meshlets.  Every early return is taken by the whole workgroup.
-template <int LOSS, int MODE>
+// share of the tile's meshlets.  Every early return is taken by the whole workgroup.  CLIP: the instantiation that can cut
+// triangles at the near plane — a kernel of its own, launched when the camera is close enough to the robot for that to
+// happen at all (the host decides from the robot's reach, launch_raster): with the clipping code present the register
+// allocation of everything else suffers (4 - 8 % on the bench workload, wherever the code sits: measured).
+template <int LOSS, int MODE, bool CLIP>
 __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotParams &rp, const RasterArgs &ra, const int row,
                                             const int tile_id, const int zme, const int zsplit)
 {
@@ -677,6 +799,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
     __shared__ int s_qoff[NWAVES][64];
     __shared__ unsigned long long s_qmask[NWAVES][TILE_H > 64 ? TILE_H : 64];   // one word per chunk of 64 row items: at most 64 triangles x TILE_H rows
     __shared__ int s_next;
+    __shared__ int s_near;                            // the list holds a meshlet that reaches the near plane
     __shared__ uint32_t s_keep[NWAVES][MESHLET_MAX_TRIS];
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
@@ -715,7 +838,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
         }
         return;
     }
-    if (tid == 0) { s_count = 0; s_next = 0; }
+    if (tid == 0) { s_count = 0; s_next = 0; s_near = 0; }
     if (tid < ROPE_SUM_WORDS) lds_sums[tid] = 0;
     __syncthreads();
 
@@ -731,10 +854,11 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
         for (int m = m_begin + tid; m < m_end; m += NTHREADS) {
             if (zsplit > 1 && (m % zsplit) != zme) continue;       // this workgroup's share of the meshlets
             const short4 b = bb[m];
-            const int bx0 = b.x & 0x3FFF;
+            const int bx0 = b.x & 0x1FFF;
             if (bx0 <= b.y && bx0 <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
                 int pos = atomicAdd(&s_count, 1);
-                s_list[pos] = (uint16_t)(m | ((b.x & 0x4000) ? 0x8000 : 0));
+                s_list[pos] = (uint16_t)(m | ((b.x & 0x4000) ? 0x8000 : 0) | ((b.x & 0x2000) ? 0x4000 : 0));
+                if (b.x & 0x2000) s_near = 1;                       // some meshlet of this tile takes the clipping pass below
             }
         }
     }
@@ -797,15 +921,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
                         const int w = x1 - x0 + 1, h = y1 - y0 + 1;
                         if (big >= EDGE_COEF_LIMIT) {
                             // enormous triangle (edge extent >= 16384 px): exact 64-bit walk, one lane
-                            const int64_t b01 = owns(a.X, a.Y, b.X, b.Y) ? 0 : -1, b12 = owns(b.X, b.Y, c.X, c.Y) ? 0 : -1,
-                                          b20 = owns(c.X, c.Y, a.X, a.Y) ? 0 : -1;
-                            for (int py = y0; py <= y1; py++)
-                                for (int px = x0; px <= x1; px++) {
-                                    const int32_t fx = px * 256 + 128, fy = py * 256 + 128;
-                                    if (((edge_fn(a.X, a.Y, b.X, b.Y, fx, fy) + b01) | (edge_fn(b.X, b.Y, c.X, c.Y, fx, fy) + b12) |
-                                         (edge_fn(c.X, c.Y, a.X, a.Y, fx, fy) + b20)) < 0) continue;
-                                    depth_test_write(tile, px - col0, py - tf.vy0, pl, (float)(px - pxa), (float)(py - pya), l);
-                                }
+                            raster_exact(tile, a, b, c, l, tf, wx0, wx1, wy0, wy1);
                         } else if (w <= SMALL_TRI_COLS && h <= SMALL_TRI_ROWS) {
                             // small box: walk its rows, four samples of a row at a time without branching on coverage tests
                             if (!ROPE_SKIP(fp, 32)) {
@@ -910,7 +1026,8 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
         li = __builtin_amdgcn_readfirstlane(li);
         if (li >= n_list) break;
         const int m_entry = __builtin_amdgcn_readfirstlane((int)s_list[li]);
-        const int m = m_entry & 0x7FFF;
+        if (CLIP && (m_entry & 0x4000)) continue;         // reaches the near plane: drawn by the clipping pass after this loop
+        const int m = m_entry & 0x3FFF;
         const bool compact = (m_entry & 0x8000) != 0;     // wave-uniform: chooses the 32-bit set-up
         const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * m + 1];
         const int v0 = (int)h1.x, t0 = (int)h1.y, nv = (int)(h1.z & 0xFFFF), nt = (int)(h1.z >> 16);
@@ -985,6 +1102,15 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
         __builtin_amdgcn_wave_barrier();
     }
     if (pend_n > 0) pass2(pend_n, pend_compact);
+    if (CLIP && s_near) {
+        // the meshlets that reach the near plane (bounds_kernel), one per wave at a time: cut and drawn triangle by triangle
+        for (int li = wave; li < n_list; li += NWAVES) {
+            const int m_entry = __builtin_amdgcn_readfirstlane((int)s_list[li]);
+            if (!(m_entry & 0x4000)) continue;
+            const uint4 h1 = reinterpret_cast<const uint4 *>(rp.ml_header)[2 * (m_entry & 0x3FFF) + 1];
+            clipped_meshlet(tile, s_mvp + 16 * h1.w, rp.ml_verts + 3 * (size_t)h1.x, rp.ml_tris + h1.y, (int)(h1.z >> 16), h1.w, hw, hh, tf, wx0, wx1, wy0, wy1);
+        }
+    }
     __syncthreads();
 
     if (MODE == MODE_LAYER) {
@@ -1059,7 +1185,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
 // MODE_SCORE: reduce the loss and add (actual - empty) into the candidate's sums.
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
-template <int LOSS, int MODE>
+template <int LOSS, int MODE, bool CLIP>
 __global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
 raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 {
@@ -1068,14 +1194,14 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     // would pile up there.  Rotating the tile index by a per-row hash spreads every tile over all XCDs.
     const int n_tiles_all = fp.tiles_x * fp.tiles_y;
     const int tile_id = (int)((blockIdx.x + ((blockIdx.y * 0x9E3779B1u) >> 12)) % (unsigned)n_tiles_all);
-    raster_tile<LOSS, MODE>(fp, rp, ra, (int)blockIdx.y, tile_id, (MODE == MODE_SPLIT) ? (int)blockIdx.z : 0, (MODE == MODE_SPLIT) ? (int)gridDim.z : 1);
+    raster_tile<LOSS, MODE, CLIP>(fp, rp, ra, (int)blockIdx.y, tile_id, (MODE == MODE_SPLIT) ? (int)blockIdx.z : 0, (MODE == MODE_SPLIT) ? (int)gridDim.z : 1);
 }
 
 // Large batches: the (candidate, tile) pairs that have anything to draw, taken from a queue by a grid that just fills the
 // chip (two workgroups per CU) — of the tiles x candidates pairs of a pass about four in five have nothing to do, and a
 // launch over all of them spends a fifth of a millisecond starting workgroups that leave at once.  score_queue_kernel
 // builds the queue.  A workgroup asks for its next pair while it works on the current one.
-template <int LOSS>
+template <int LOSS, bool CLIP>
 __global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
 raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, int *__restrict__ counters /* [0] pairs queued, [1] next */)
 {
@@ -1090,7 +1216,7 @@ raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_
         int next = 0;
         if (threadIdx.x == 0) next = atomicAdd(&counters[1], 1);      // in flight while this pair is drawn
         const uint32_t it = items[item];
-        raster_tile<LOSS, MODE_SCORE>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);
+        raster_tile<LOSS, MODE_SCORE, CLIP>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);
         __syncthreads();                                   // the tile's LDS is free again
         if (threadIdx.x == 0) s_item = next;
         __syncthreads();
@@ -1311,9 +1437,17 @@ __global__ void resolve_kernel(const uint32_t *__restrict__ key, int n, float c_
 
 // ------------------------------------------------------------ launch helpers ---
 template <int LOSS, int MODE>
-static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a)
+static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a, bool clip)
 {
-    hipLaunchKernelGGL((raster_score_kernel<LOSS, MODE>), grid, dim3(NTHREADS), 0, st, fp, rp, a);
+    if (clip) hipLaunchKernelGGL((raster_score_kernel<LOSS, MODE, true>), grid, dim3(NTHREADS), 0, st, fp, rp, a);
+    else hipLaunchKernelGGL((raster_score_kernel<LOSS, MODE, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a);
+}
+
+template <int LOSS>
+static void launch_queue_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a, uint32_t *items, int *counters, bool clip)
+{
+    if (clip) hipLaunchKernelGGL((raster_queue_kernel<LOSS, true>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, counters);
+    else hipLaunchKernelGGL((raster_queue_kernel<LOSS, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, counters);
 }
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
@@ -1346,39 +1480,39 @@ hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const Fra
 }
 
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                         const RasterArgs &a)
+                         const RasterArgs &a, bool clip)
 {
     dim3 grid(fp.tiles_x * fp.tiles_y, rows, mode == MODE_SPLIT ? a.split : 1);
-    if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a);
-    else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a);
-    else if (mode == MODE_TABLE) launch_one<ROPE_LOSS_LOOKUP, MODE_TABLE>(grid, st, fp, rp, a);
-    else if (mode == MODE_SPLIT) launch_one<ROPE_LOSS_DEPTH, MODE_SPLIT>(grid, st, fp, rp, a);
+    if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a, clip);
+    else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a, clip);
+    else if (mode == MODE_TABLE) launch_one<ROPE_LOSS_LOOKUP, MODE_TABLE>(grid, st, fp, rp, a, clip);
+    else if (mode == MODE_SPLIT) launch_one<ROPE_LOSS_DEPTH, MODE_SPLIT>(grid, st, fp, rp, a, clip);
     else if (mode == MODE_LAYER) {
-        if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a);
-        else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a);
-        else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_LAYER>(grid, st, fp, rp, a);
-        else launch_one<ROPE_LOSS_TSWEEP, MODE_LAYER>(grid, st, fp, rp, a);
+        if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a, clip);
+        else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a, clip);
+        else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_LAYER>(grid, st, fp, rp, a, clip);
+        else launch_one<ROPE_LOSS_TSWEEP, MODE_LAYER>(grid, st, fp, rp, a, clip);
     }
-    else if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_SCORE>(grid, st, fp, rp, a);
-    else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_SCORE>(grid, st, fp, rp, a);
-    else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a);
-    else if (loss == ROPE_LOSS_CAMFULL) launch_one<ROPE_LOSS_CAMFULL, MODE_SCORE>(grid, st, fp, rp, a);
-    else launch_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a);
+    else if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_SCORE>(grid, st, fp, rp, a, clip);
+    else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_SCORE>(grid, st, fp, rp, a, clip);
+    else if (loss == ROPE_LOSS_LOOKUP) launch_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a, clip);
+    else if (loss == ROPE_LOSS_CAMFULL) launch_one<ROPE_LOSS_CAMFULL, MODE_SCORE>(grid, st, fp, rp, a, clip);
+    else launch_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a, clip);
     return hipGetLastError();
 }
 
 hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                               const RasterArgs &a, uint32_t *items, int *counters)
+                               const RasterArgs &a, uint32_t *items, int *counters, bool clip)
 {
     const int n_tiles = fp.tiles_x * fp.tiles_y;
     hipLaunchKernelGGL(score_queue_kernel, dim3(rows, a.mask_words), dim3(32), 0, st, a, n_tiles, items, counters);
-    const dim3 grid(workgroups), block(NTHREADS);
+    const dim3 grid(workgroups);
     switch (loss) {
-    case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_DEPTH>, grid, block, 0, st, fp, rp, a, items, counters); break;
-    case ROPE_LOSS_FULL: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_FULL>, grid, block, 0, st, fp, rp, a, items, counters); break;
-    case ROPE_LOSS_LOOKUP: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_LOOKUP>, grid, block, 0, st, fp, rp, a, items, counters); break;
-    case ROPE_LOSS_CAMFULL: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_CAMFULL>, grid, block, 0, st, fp, rp, a, items, counters); break;
-    default: hipLaunchKernelGGL(raster_queue_kernel<ROPE_LOSS_TSWEEP>, grid, block, 0, st, fp, rp, a, items, counters); break;
+    case ROPE_LOSS_DEPTH: launch_queue_one<ROPE_LOSS_DEPTH>(grid, st, fp, rp, a, items, counters, clip); break;
+    case ROPE_LOSS_FULL: launch_queue_one<ROPE_LOSS_FULL>(grid, st, fp, rp, a, items, counters, clip); break;
+    case ROPE_LOSS_LOOKUP: launch_queue_one<ROPE_LOSS_LOOKUP>(grid, st, fp, rp, a, items, counters, clip); break;
+    case ROPE_LOSS_CAMFULL: launch_queue_one<ROPE_LOSS_CAMFULL>(grid, st, fp, rp, a, items, counters, clip); break;
+    default: launch_queue_one<ROPE_LOSS_TSWEEP>(grid, st, fp, rp, a, items, counters, clip); break;
     }
     return hipGetLastError();
 }

@@ -61,7 +61,7 @@ def test_full_grid_layers_equal_direct_rendering(full):
     for loss in (eng.LOSS_DEPTH, eng.LOSS_FULL):
         _, sums_a, bi_a, _ = e.eval(cand, 6, loss, want_sums=True)
         # no shared layers at all; layers without the second level (per q0); one workgroup per (tile, candidate) instead of the queue
-        for flag in (e.NO_LAYERS, e.NO_PARENTS, e.NO_QUEUE, e.NO_LAYERS | e.NO_QUEUE):
+        for flag in (e.NO_LAYERS, e.NO_PARENTS, e.NO_QUEUE, e.NO_LAYERS | e.NO_QUEUE, e.CLIP_KERNELS):
             e.set_strategy(flag)
             try:
                 _, sums_b, bi_b, _ = e.eval(cand, 6, loss, want_sums=True)
@@ -135,6 +135,25 @@ def test_robot_partly_and_wholly_out_of_view():
     d_ref, id_ref = o.render([0.5, 0.5, 0.5, 0, 0, 0], 6)
     d, ids = e.render([0.5, 0.5, 0.5, 0, 0, 0], 6)
     assert np.array_equal(ids, id_ref) and np.array_equal(d.view(np.uint32), d_ref.view(np.uint32))
+    # a camera 0.2 m from the upper arm, and one inside the robot's envelope: triangles reach and cross the near plane (5 cm)
+    # and are cut there, as OpenGL cuts them (render.py:92-98, projection.py:161-169) — images, sums and errors bit for bit
+    # (0.2 m in front of the forearm: nothing crosses yet; 0.12 m, tilted: 1 800 triangles do; inside the envelope: 700 - 1 300)
+    for pose, q in (([0.3, -0.2, 0.77, 0, 0, 0], [0, 0, 0, 0, 0, 0]), ([0.3, -0.12, 0.77, 0, 0.2, 0.3], [0, 0, 0, 0, 0, 0]),
+                    ([0.2, -0.1, 0.6, 0.3, 0.1, -0.4], [0.5, 0.4, 0.6, 0.2, 0.3, 0.1]), ([0.05, -0.12, 0.25, 0, -0.4, 0.1], [0, 0, 0, 0, 0, 0]),
+                    ([0.4, -0.06, 0.8, 0, 0, 0.5], [0, 0.3, 0.2, 0, 0, 0])):
+        ec, intrc, PVc = make_engine(rb, '640_480_color', pose=pose, ds=2)
+        oc = helpers.make_oracle(rb, intrc, PVc)
+        d_ref, id_ref = oc.render(q, 6)
+        d, ids = ec.render(q, 6)
+        assert (id_ref != 255).mean() > 0.2, pose                      # the robot fills a good part of the view
+        assert np.array_equal(ids, id_ref) and np.array_equal(d.view(np.uint32), d_ref.view(np.uint32)), pose
+        tq, t32, flags, *_ = helpers.synthetic_target(d_ref, id_ref)
+        ec.set_target(tq, t32, flags)
+        cand = np.array(q) + np.random.default_rng(2).uniform(-.3, .3, (40, 6))
+        for c_ in (cand, cand[:3]):                                    # the big-batch and the small-batch (split) launch
+            err_ref, sums_ref = oc.eval(c_, eng.LOSS_FULL, 6, tq, t32, None, flags, threads=8, want_sums=True)
+            err, sums, _, _ = ec.eval(c_, 6, eng.LOSS_FULL, want_sums=True)
+            assert np.array_equal(sums, sums_ref) and np.array_equal(err.view(np.uint64), err_ref.view(np.uint64)), pose
     e2, intr2, PV2 = make_engine(rb, '640_480_color', pose=[0, -1.5, 0.75, 0, 0, 3.1], ds=2)     # looking away
     d, ids = e2.render([0, 0, 0, 0, 0, 0], 6)
     assert (ids == 255).all() and (d == 0).all()

@@ -129,6 +129,35 @@ def test_nearer_surface_wins_and_depth_is_metric():
     assert (d[ids == 255] == 0).all()
 
 
+def test_near_plane_clipping_against_an_analytic_floor():
+    """OpenGL clips primitives against the view volume before the viewport transform (pyrender draws through GL; znear 0.05 m,
+    projection.py:161-169): a floor quad that runs from half a metre BEHIND the camera to four metres in front of it must
+    still cover every pixel whose ray meets it beyond the near plane, at the ray's metric depth.  Without clipping both of
+    its triangles would vanish (a vertex behind the eye has no window position)."""
+    y0 = -0.3
+    a, b, c, d = [-1, y0, 0.5], [1, y0, 0.5], [1, y0, -4.0], [-1, y0, -4.0]          # normal +y: seen from above, CCW
+    o = _flat_scene([[[a, b, c], [a, c, d]]])
+    depth, ids = o.render(np.zeros(6), 1)
+    px, py = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)                     # window coordinates, y up
+    dx, dy = (px - 32) / 64, (py - 24) / 64                                          # ray (dx, dy, -1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = np.where(dy < 0, y0 / dy, np.inf)                                        # distance along -z where the ray meets the floor
+    inside = (t > ZNEAR) & (t < 4.0) & (np.abs(dx * t) < 1.0)
+    # pixels whose ray passes within a hair of a boundary of the visible region are left out of the comparison
+    edge = (np.abs(t - ZNEAR) < 1e-3) | (np.abs(t - 4.0) < 2e-2) | (np.abs(np.abs(dx * t) - 1.0) < 2e-2)
+    got = (ids == 0)[::-1]                                                            # image row 0 is the top: flip to y up
+    z = depth[::-1]
+    assert inside.sum() > 500
+    assert np.array_equal(got[~edge], inside[~edge])
+    m = inside & ~edge
+    assert np.abs(z[m] - t[m]).max() < 2e-4 * 4.0
+    # both triangles have a vertex behind the eye: the whole visible floor, bottom row of the image included, exists only
+    # because they are cut at the plane rather than dropped
+    assert got[0].all() and got.sum() > 1000
+    # the same floor seen from below is back-facing after clipping as well
+    assert (_flat_scene([[[a, c, b], [a, d, c]]]).render(np.zeros(6), 1)[1] == 255).all()
+
+
 def test_equal_depth_lower_link_id_wins():
     q = _quad(24, 16, 40, 40)
     d, ids = _flat_scene([list(q), list(q)]).render(np.zeros(6), 2)
