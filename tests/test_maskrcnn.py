@@ -238,3 +238,35 @@ def test_batched_nms_equals_set_by_set():
         want += ix[_nms(boxes[0, ix], scores[0, ix], 0.3, N)].tolist()
     assert sorted(keep.nonzero().squeeze(1).tolist()) == sorted(want)
     assert _nms_batched(boxes[:, :0], scores[:, :0], 0.3, 5).shape == (B, 0)
+
+
+def test_inference_configuration_is_the_references():
+    """What the reference's own calls fix about the network, asserted against this module's constants:
+    train.py:49 — modelConfig(network_backbone="resnet101", num_classes=len(class_names)) with class_names = the renderer's
+    colour dictionary (one entry per rendered link, render.py:155-163); predict.py:97 — inferConfig(num_classes=6,
+    class_names=["BG"] + mesh_names[:6]).  PixelLib 0.5.6 (requirements.txt; absent here) turns both into Matterport's Config
+    with NUM_CLASSES = 1 + num_classes and, for inference, its published defaults: 512 x 512 square input,
+    detection_threshold 0.7, RPN (32..512) x (0.5, 1, 2), 6000 -> NMS 0.7 -> 1000 proposals, 100 detections at NMS 0.3,
+    7 / 14 / 28 pooling and mask sizes, 256-channel pyramid, 1024-wide classifier head, MEAN_PIXEL (123.7, 116.8, 103.9)."""
+    import inspect
+    from rope_s3d_amd import maskrcnn as M
+    from rope_s3d_amd.constants import NUM_RENDER_LINKS
+    from rope_s3d_amd.urdf import URDFReader
+    links = URDFReader().mesh_names[:6]                                   # predict.py:88-91: classes = ["BG"] + these
+    assert len(links) == NUM_RENDER_LINKS == 6
+    sig = inspect.signature(M.MaskRCNN.__init__).parameters
+    assert sig['num_classes'].default == 1 + len(links) == 7             # NUM_CLASSES = 1 + num_classes (background)
+    assert sig['image_size'].default == 512 and sig['min_confidence'].default == 0.7
+    assert inspect.signature(M.MaskRCNNSegmenter.__init__).parameters['num_classes'].default == 7
+    net = M.MaskRCNN()
+    # ResNet-101: 3 + 4 + 23 + 3 bottleneck blocks (train.py:49 network_backbone="resnet101")
+    blocks = [len(list(stage.children())) for stage in net.backbone.stages]
+    assert blocks == [3, 4, 23, 3]
+    assert net.cls.out_features == 7 and net.box.out_features == 7 * 4 and list(net.mask.children())[-1].out_channels == 7
+    assert (M.RPN_ANCHOR_SCALES, M.RPN_ANCHOR_RATIOS) == ((32, 64, 128, 256, 512), (0.5, 1.0, 2.0))
+    assert (M.PRE_NMS_LIMIT, M.POST_NMS_ROIS, M.RPN_NMS_THRESHOLD) == (6000, 1000, 0.7)
+    assert (M.DETECTION_MAX_INSTANCES, M.DETECTION_NMS_THRESHOLD) == (100, 0.3)
+    assert (M.POOL_SIZE, M.MASK_POOL_SIZE, M.MASK_SHAPE) == (7, 14, 28)
+    assert (M.TOP_DOWN_PYRAMID_SIZE, M.FPN_CLASSIF_FC) == (256, 1024)
+    assert M.MEAN_PIXEL == (123.7, 116.8, 103.9)
+    assert M.RPN_BBOX_STD_DEV == M.BBOX_STD_DEV == (0.1, 0.1, 0.2, 0.2)
