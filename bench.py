@@ -134,6 +134,9 @@ def main():
                          "mh50, 1280x720, 32^3 candidates")
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-unshared', action='store_true',
+                    help="skip the extra passes behind unshared_value (profiling runs: they launch the same kernels on six links per "
+                         "candidate and would mix into the per-kernel averages)")
     ap.add_argument('--loss', default='depth', choices=['depth', 'full'],
                     help="depth = the metric's loss (last term of Predictor._error); full = the whole _error with the link masks "
                          "(SURVEY §8d: +2*W*H bytes per candidate for the id image)")
@@ -264,10 +267,12 @@ def main():
 
     # outside the timed region: the same candidates with nothing shared between them (six links drawn per candidate) —
     # the rate a caller sees when no two candidates agree in their first two joint angles
-    e.set_strategy(e.NO_LAYERS)
-    e.eval_resident(6, loss)
-    kern_u = e.profile_eval(6, loss, None, reps=max(2, min(args.steps, 5)))
-    e.set_strategy(0)
+    kern_u = None
+    if not args.no_unshared:
+        e.set_strategy(e.NO_LAYERS)
+        e.eval_resident(6, loss)
+        kern_u = e.profile_eval(6, loss, None, reps=max(2, min(args.steps, 5)))
+        e.set_strategy(0)
 
     if rank == 0:
         poses = (C_total if args.split_candidates else world * C) * args.steps
@@ -300,7 +305,7 @@ def main():
                        "parallelism": f"candidates of one frame /{world}" if args.split_candidates else f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
             "ranks_seen": ranks_seen,
-            "unshared_value": C / (kern_u['total'] * 1e-3),
+            "unshared_value": C / (kern_u['total'] * 1e-3) if kern_u else None,
             "unshared_note": "poses/s per GPU with rope_set_strategy(NO_LAYERS): links 0-2 drawn for every candidate instead of once "
                              "per distinct (S, L); same results bit for bit; measured after the timed region",
             # SURVEY §8d's contract: algorithmic bytes per candidate x candidates per launch / live launch time against the HBM
@@ -312,7 +317,7 @@ def main():
                          "measured_hbm_frac": (traffic / (kern['score'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "binding_resource": "vector instruction issue (valu_issue below), not HBM",
                          "valu_issue": valu,
-                         "kernel": "raster_score_kernel<%s,SCORE> (+ its <%s,LAYER> launches: links 0-2 once per distinct (S,L))" % ((args.loss.upper(),) * 2),
+                         "kernel": "raster_queue_kernel<%s> (per-candidate links + loss, from the queue of (candidate, tile) pairs) + raster_score_kernel<%s,LAYER> launches (links 0-2 once per distinct (S,L))" % ((args.loss.upper(),) * 2),
                          "kernel_ms": kern['raster'], "score_launch_ms": kern['score'], "layer_launch_ms": kern['layer'],
                          "bytes_per_candidate": b_cand, "candidates_per_launch": C,
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
