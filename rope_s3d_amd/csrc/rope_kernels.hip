@@ -1223,29 +1223,34 @@ raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_
     }
 }
 
-// The queue of raster_queue_kernel: one workgroup per (candidate, word of its tile masks).  Pairs whose tile the
-// candidate's own links reach (or, without shared layers, any of its links) are queued by the first 32 threads; where only
-// the shared layer reaches, the candidate takes the layer's stored loss sums here and now — eight groups of 32 threads
-// share those tiles, so that their loads are in flight together.
+// The queue of raster_queue_kernel: 32 threads per (candidate, word of its tile masks), eight candidates per workgroup.
+// Pairs whose tile the candidate's own links reach (or, without shared layers, any of its links) are queued — one atomic
+// on the queue's counter per workgroup: thousands of them on one address are served one after the other (40 us for the
+// 4096 candidates of the bench with one atomic each); where only the shared layer reaches, the candidate takes the
+// layer's stored loss sums here and now.
 __global__ void __launch_bounds__(256)
-score_queue_kernel(RasterArgs ra, int n_tiles, uint32_t *__restrict__ items, int *__restrict__ counters)
+score_queue_kernel(RasterArgs ra, int n_rows, int n_tiles, uint32_t *__restrict__ items, int *__restrict__ counters)
 {
-    const int cand = blockIdx.x, w = blockIdx.y, k = threadIdx.x & 31, slot = threadIdx.x >> 5;
-    const uint32_t hi = ra.mask_hi[(size_t)cand * ra.mask_words + w];
-    const bool layers = ra.layer_of != nullptr;
-    const uint32_t lo = ra.mask_lo[(size_t)(layers ? ra.layer_rep[ra.layer_of[cand]] : cand) * ra.mask_words + w];
+    __shared__ int s_n[8], s_base;
+    const int k = threadIdx.x & 31, slot = threadIdx.x >> 5, cand = 8 * blockIdx.x + slot, w = blockIdx.y;
+    const bool live = cand < n_rows, layers = ra.layer_of != nullptr;
+    const uint32_t hi = live ? ra.mask_hi[(size_t)cand * ra.mask_words + w] : 0u;
+    const uint32_t lo = live ? ra.mask_lo[(size_t)(layers ? ra.layer_rep[ra.layer_of[cand]] : cand) * ra.mask_words + w] : 0u;
     const uint32_t work = layers ? hi : (hi | lo);
-    if (slot == 0) {
-        int base = 0;
-        if (k == 0 && work) base = atomicAdd(&counters[0], __popc(work));
-        base = __shfl(base, 0, 32);
-        if ((work >> k) & 1u) items[base + __popc(work & ((1u << k) - 1u))] = (uint32_t)cand | ((uint32_t)(32 * w + k) << 16);
+    if (k == 0) s_n[slot] = __popc(work);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int i = 0; i < 8; i++) total += s_n[i];
+        s_base = total ? atomicAdd(&counters[0], total) : 0;
     }
-    if (layers && k < ROPE_SUM_WORDS) {
+    __syncthreads();
+    int base = s_base;
+    for (int i = 0; i < slot; i++) base += s_n[i];
+    if ((work >> k) & 1u) items[base + __popc(work & ((1u << k) - 1u))] = (uint32_t)cand | ((uint32_t)(32 * w + k) << 16);
+    if (layers && live && k < ROPE_SUM_WORDS) {
         uint64_t acc = 0;
-        int i = 0;
-        for (uint32_t only = lo & ~hi; only; only &= only - 1, i++) {
-            if ((i & 7) != slot) continue;
+        for (uint32_t only = lo & ~hi; only; only &= only - 1) {
             const int tile = 32 * w + __ffs((int)only) - 1;
             acc += ra.layer_sums[((size_t)ra.layer_of[cand] * n_tiles + tile) * ROPE_SUM_WORDS + k];
         }
@@ -1510,7 +1515,7 @@ hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t s
                                const RasterArgs &a, uint32_t *items, int *counters, bool clip)
 {
     const int n_tiles = fp.tiles_x * fp.tiles_y;
-    hipLaunchKernelGGL(score_queue_kernel, dim3(rows, a.mask_words), dim3(256), 0, st, a, n_tiles, items, counters);
+    hipLaunchKernelGGL(score_queue_kernel, dim3((rows + 7) / 8, a.mask_words), dim3(256), 0, st, a, rows, n_tiles, items, counters);
     const dim3 grid(workgroups);
     switch (loss) {
     case ROPE_LOSS_DEPTH: launch_queue_one<ROPE_LOSS_DEPTH>(grid, st, fp, rp, a, items, counters, clip); break;
