@@ -172,6 +172,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
     if (!c) return ROPE_E_NOMEM;
     c->device = device;
     if (const char *e = std::getenv("ROPE_SPLIT_TARGET")) c->split_target = std::max(1, std::atoi(e));     // tuning aid
+    if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 31;                     // tuning aid: rope_set_strategy's bits
     if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
