@@ -667,11 +667,20 @@ __device__ static inline Plane make_plane(const SVert &a, const SVert &b, const 
     return plane_from(a, b, c, (float)(double)area2, (float)(double)E20a, (float)(double)E01a);
 }
 
+// rint(d * (2^24 - 1)) clamped to [0, 2^24 - 1], NaN -> 0: `!(qf >= 0) ? 0 : (qf >= 16777215 ? D24_MAX : (uint32_t)qf)` of
+// the specification.  v_cvt_u32_f32 saturates by itself — NaN and negatives give 0, large values 2^32 - 1 — so one conversion
+// and one minimum say the same for every input (the C cast alone would be undefined out of range, hence the instruction).
+__device__ static inline uint32_t depth24(float d)
+{
+    const float qf = rintf(d * 16777215.0f);
+    uint32_t q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(qf));
+    return min(q, D24_MAX);
+}
+
 __device__ static inline void depth_test_write(uint32_t *tile, int u, int v, const Plane &pl, float dx, float dy, uint32_t link)
 {
-    const float d = fmaf(pl.gx, dx, fmaf(pl.gy, dy, pl.dc));
-    const float qf = rintf(d * 16777215.0f);
-    const uint32_t d24 = !(qf >= 0.0f) ? 0u : (qf >= 16777215.0f ? D24_MAX : (uint32_t)qf);
+    const uint32_t d24 = depth24(fmaf(pl.gx, dx, fmaf(pl.gy, dy, pl.dc)));
     if (d24 < D24_MAX)                              // GL_LESS against the cleared depth of 1.0
         atomicMin(&tile[(TILE_H - 1 - v) * TILE_W + u], (d24 << 8) | link);
 }
@@ -1009,12 +1018,16 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
                     clip_span(e0, c, lo, hi);
                     clip_span(e1, c, lo, hi);
                     clip_span(e2, c, lo, hi);
-                    if (tall) {
-                        const float dx = (float)(c + dxa);
-                        for (int v = lo; v <= hi; v++) depth_test_write(tile, c, v, pl, dx, (float)(v + dya), lq);
-                    } else {
-                        const float dy = (float)(c + dya);
-                        for (int u = lo; u <= hi; u++) depth_test_write(tile, u, c, pl, (float)(u + dxa), dy, lq);
+                    // one loop for rows and columns alike: a chunk usually holds both kinds, and two loops one after the
+                    // other each run as long as their own longest span.  Sample i of the line: (u, v) = (c, i) for a
+                    // column, (i, c) for a row; same operands and operation order as depth_test_write either way.
+                    const float fixf = (float)(c + (tall ? dxa : dya));
+                    const int var_off = tall ? dya : dxa, step = tall ? -TILE_W : 1;
+                    int idx = tall ? (TILE_H - 1 - lo) * TILE_W + c : (TILE_H - 1 - c) * TILE_W + lo;
+                    for (int i = lo; i <= hi; i++, idx += step) {
+                        const float varf = (float)(i + var_off);
+                        const uint32_t d24 = depth24(fmaf(pl.gx, tall ? fixf : varf, fmaf(pl.gy, tall ? varf : fixf, pl.dc)));
+                        if (d24 < D24_MAX) atomicMin(&tile[idx], (d24 << 8) | lq);          // GL_LESS against the cleared depth of 1.0
                     }
                 }
             }
