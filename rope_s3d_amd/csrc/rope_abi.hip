@@ -89,7 +89,9 @@ struct rope_ctx {
     uint32_t *d_gtile = nullptr;
     size_t gtile_cap = 0;
     bool gtile_dirty = true;
-    int split_target = 6144, split_cap = 32;   // workgroups aimed at per launch / most workgroups per (tile, candidate)
+    // MODE_SPLIT: busy workgroups aimed at per launch (one generation: 2 per CU), fewest / most per (tile, candidate), and the
+    // workgroups per launch of the scoring pass that follows.  Measured at 160x90, 640x360 and 640x480 (tools/r02_split_tune.sh).
+    int split_target = 512, split_min = 8, split_min_many = 3, split_cap = 64, score_target = 6144;
     int strategy = 0;                          // STRATEGY_* bits (rope_set_strategy): launch structure only, never a result
     // large batches: queue of the (candidate, tile) pairs with something to draw, worked off by a grid that just fills the chip
     uint32_t *d_qitems = nullptr;
@@ -174,6 +176,8 @@ extern "C" int rope_create(rope_ctx **out, int device)
     if (const char *e = std::getenv("ROPE_SPLIT_TARGET")) c->split_target = std::max(1, std::atoi(e));     // tuning aid
     if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 31;                     // tuning aid: rope_set_strategy's bits
     if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("ROPE_SPLIT_MIN")) c->split_min = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("ROPE_SPLIT_MIN_MANY")) c->split_min_many = std::max(1, std::min(64, std::atoi(e)));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete c;
@@ -678,8 +682,13 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     // so the meshlets of each tile are split over several workgroups that merge into a tile in global memory.
     int split = 1;
     if (!layers && !(c->strategy & STRATEGY_NO_SPLIT)) {
-        split = std::min(c->split_cap, c->split_target / std::max(1, c->C * c->n_tiles));
-        if (split < 2) split = 1;
+        // about a third of a frame's tiles hold the robot (all of them when the frame is one or two tiles): the others' workgroups
+        // leave at once.  Too few shares per tile make each workgroup's chain of meshlets long: a floor, lower once the
+        // launch runs to several generations of workgroups anyway (every share pays for clearing and scanning its LDS tile).
+        const int busy_tiles = std::max(std::min(2, c->n_tiles), c->n_tiles / 3);
+        const int floor_ = c->C * busy_tiles <= 256 ? c->split_min : c->split_min_many;
+        split = std::max(std::min(c->split_cap, c->split_target / std::max(1, c->C * busy_tiles)), std::min(floor_, c->split_cap));
+        if (split < 2 || c->C * busy_tiles > 4 * c->split_target) split = 1;       // enough (tile, candidate) pairs to fill the chip whole
     }
     if (split > 1) {
         const size_t need = (size_t)c->C * c->n_tiles * (TILE_W * TILE_H);
@@ -709,7 +718,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     if (split > 1) {
         int slices = 1;
-        while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->split_target) slices *= 2;
+        while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->score_target) slices *= 2;
         HIP_TRY(c, launch_score_gtile(loss, c->C, slices, c->stream, fp, a));
         c->gtile_dirty = ROPE_SKIP(fp, ~0);
     } else if (c->C > 256 && !(c->strategy & STRATEGY_NO_QUEUE)) {
