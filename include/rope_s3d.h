@@ -222,6 +222,33 @@ int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop
 enum { ROPE_STRATEGY_NO_LAYERS = 1, ROPE_STRATEGY_NO_SPLIT = 2, ROPE_STRATEGY_NO_PARENTS = 4, ROPE_STRATEGY_NO_QUEUE = 8, ROPE_STRATEGY_CLIP_KERNELS = 16 };
 int rope_set_strategy(rope_ctx *ctx, int flags);
 
+/* ---- Segmentation stage (robotpose/prediction/predict.py:94-98,416: the Matterport Mask R-CNN in front of the engine).
+ * The convolutions are library calls from PyTorch-ROCm (rope_s3d_amd/maskrcnn.py); the two box-shaped steps between them
+ * are kernels of this library.  No context: plain device pointers and the HIP stream to launch on (hipStream_t, NULL = default).
+ *
+ * rope_seg_nms: greedy non-maximum suppression (tf.image.non_max_suppression, as the ProposalLayer and
+ * refine_detections_graph of mrcnn/model.py call it) of n_sets independent sets of n boxes each.
+ *   boxes    n_sets x n x 4 float32 (y1, x1, y2, x2), each set sorted by DESCENDING score; 16-byte aligned
+ *   groups   n_sets x n int32 or NULL: boxes only suppress boxes of the same group (per-class NMS)
+ *   valid    n_sets x n bytes or NULL: 0 = padding (never kept, never suppressing)
+ *   limit    at most this many boxes kept per set (the best ones)
+ *   scratch  n_sets x n x ceil(n / 64) uint64 of device memory
+ *   keep     n_sets x n bytes out: 1 = kept (in the order of `boxes`)
+ *
+ * rope_seg_roi_align: PyramidROIAlign — the pyramid level by box area, then tf.image.crop_and_resize (bilinear,
+ * pool x pool samples spanning the box, corners included, 0 outside the map).
+ *   rows_bf16       the pyramid levels P2..P5 of all frames as one table of channel rows (bfloat16, `channels` per
+ *                   feature pixel), level l starting at row level_off[l], frames back to back inside a level
+ *   boxes           n_boxes x 4 float32 normalised (y1, x1, y2, x2); 16-byte aligned;  frame: n_boxes int32 batch entry
+ *   level_hw        4 x (H, W) int32;  level_off 4 int64
+ *   inv_level_unit  1 / (224 / image_size) as float32;  t: `pool` float32 sample positions in [0, 1] (device)
+ *   out_bf16        n_boxes x pool x pool x channels bfloat16 */
+int rope_seg_nms(const float *boxes, const int32_t *groups, const uint8_t *valid, int n_sets, int n, float iou_thr, int limit,
+                 uint64_t *scratch, uint8_t *keep, void *stream);
+int rope_seg_roi_align(const void *rows_bf16, const float *boxes, const int32_t *frame, const int32_t *level_hw,
+                       const int64_t *level_off, int n_boxes, int channels, int pool, float inv_level_unit, const float *t,
+                       void *out_bf16, void *stream);
+
 /* Phase-skipping switches for kernel ablations (rope_debug_skip) exist only in the profiling build of the library
  * (librope_hip_profile.so, `python tools/build_variants.py profile`, -DROPE_PROFILE); this library does not export them. */
 

@@ -5,7 +5,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'librope_hip.so')
-_SOURCES = ['rope_kernels.hip', 'rope_abi.hip', 'rope_predict.cpp', 'rope_meshlets.cpp']
+_SOURCES = ['rope_kernels.hip', 'rope_abi.hip', 'rope_seg.hip', 'rope_predict.cpp', 'rope_meshlets.cpp']
 _DEPS = _SOURCES + ['rope_kernels.h', os.path.join('..', '..', 'include', 'rope_s3d.h')]
 
 # -ffp-contract=off: the arithmetic contract with the CPU oracle is "one IEEE operation per

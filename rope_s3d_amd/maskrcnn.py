@@ -139,6 +139,25 @@ def _build_pyramid_anchors(size: int, device) -> torch.Tensor:
     return (a - shift) / scale
 
 
+_SEG_LIB = None
+
+
+def _seg_lib():
+    """librope_hip.so (rope_seg.hip: NMS and pyramid RoIAlign).  On a GPU the stage's box steps run there; a missing library is an
+    error, not a reason to fall back (EngineUnavailable)."""
+    global _SEG_LIB
+    if _SEG_LIB is None:
+        from .engine import load_library
+        _SEG_LIB = load_library()
+    return _SEG_LIB
+
+
+def _seg_kernels(t: torch.Tensor) -> bool:
+    """The HIP kernels serve tensors on the GPU; ROPE_SEG_HIP=0 keeps the tensor formulation there too (equality tests, timing)."""
+    import os
+    return t.is_cuda and os.environ.get('ROPE_SEG_HIP', '1') != '0'
+
+
 def _apply_deltas(boxes, deltas):
     h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
     cy, cx = boxes[:, 0] + 0.5 * h + deltas[:, 0] * h, boxes[:, 1] + 0.5 * w + deltas[:, 1] * w
@@ -187,6 +206,22 @@ def _nms_batched(boxes: torch.Tensor, scores: torch.Tensor, thr: float, limit: i
     b = boxes.gather(1, order[..., None].expand(-1, -1, 4)).float()
     ok = torch.ones((B, N), dtype=torch.bool, device=boxes.device) if valid is None else valid.gather(1, order)
     g = None if groups is None else groups.gather(1, order)
+    if _seg_kernels(boxes):
+        # librope_hip.so: the suppression bits of all pairs in one launch, one wave per set settling them in a second
+        # (rope_seg.hip) — same overlaps, same greedy rule, no host synchronisation
+        lib = _seg_lib()
+        b = b.contiguous()
+        words = (N + 63) // 64
+        scratch = torch.empty((B, N, words), dtype=torch.int64, device=boxes.device)
+        kept = torch.empty((B, N), dtype=torch.bool, device=boxes.device)
+        g32 = None if g is None else g.to(torch.int32).contiguous()
+        okc = None if valid is None else ok.contiguous()
+        rc = lib.rope_seg_nms(b.data_ptr(), None if g32 is None else g32.data_ptr(), None if okc is None else okc.data_ptr(),
+                              B, N, float(thr), int(min(limit, N)), scratch.data_ptr(), kept.data_ptr(),
+                              torch.cuda.current_stream(boxes.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"rope_seg_nms failed ({rc})")
+        return keep_in.scatter_(1, order, kept)
     kept = torch.zeros((B, N), dtype=torch.bool, device=boxes.device)          # over the sorted order
     for start in range(0, N, block):
         blk = b[:, start:start + block]
@@ -245,6 +280,25 @@ def _roi_align(feats: List[torch.Tensor], boxes: torch.Tensor, pool: int, size: 
     K, C = len(boxes), rows.shape[1]
     if frame is None:
         frame = torch.zeros(K, dtype=torch.long, device=boxes.device)
+    if K and rows.dtype == torch.bfloat16 and _seg_kernels(boxes):
+        # librope_hip.so: level choice, the four gathers and the bilinear blend in one launch (rope_seg.hip); the same float32
+        # and bfloat16 steps as the tensor formulation below
+        lib = _seg_lib()
+        lv = feats[:4]
+        sizes = [f.shape[0] * f.shape[2] * f.shape[3] for f in lv]
+        level_hw = np.array([[f.shape[2], f.shape[3]] for f in lv], np.int32)
+        level_off = np.array([sum(sizes[:k]) for k in range(4)], np.int64)
+        rows_c, b = rows.contiguous(), boxes.float().contiguous()
+        out = torch.empty((K, pool, pool, C), dtype=torch.bfloat16, device=boxes.device)
+        t = torch.linspace(0, 1, pool, device=boxes.device)
+        inv_unit = np.float32(1.0) / np.float32(224.0 / size)                 # the tensor division by a scalar multiplies by its inverse
+        f32 = frame.to(torch.int32).contiguous()
+        rc = lib.rope_seg_roi_align(rows_c.data_ptr(), b.data_ptr(), f32.data_ptr(), level_hw.ctypes.data, level_off.ctypes.data,
+                                    K, C, pool, float(inv_unit), t.data_ptr(), out.data_ptr(),
+                                    torch.cuda.current_stream(boxes.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"rope_seg_roi_align failed ({rc})")
+        return out.permute(0, 3, 1, 2)
     b = boxes.float()
     h, w = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
     li = (4 + torch.log2((h * w).clamp(min=1e-12).sqrt() / (224.0 / size)).round()).clamp(2, 5).long() - 2

@@ -270,3 +270,92 @@ def test_inference_configuration_is_the_references():
     assert (M.TOP_DOWN_PYRAMID_SIZE, M.FPN_CLASSIF_FC) == (256, 1024)
     assert M.MEAN_PIXEL == (123.7, 116.8, 103.9)
     assert M.RPN_BBOX_STD_DEV == M.BBOX_STD_DEV == (0.1, 0.1, 0.2, 0.2)
+
+
+def _clustered_boxes(rng, B, N):
+    """Boxes around a few centres, so that many overlap: (B, N, 4) float32 in [0, 1], and scores with ties."""
+    c = rng.uniform(0.2, 0.8, (B, 12, 2))
+    pick = rng.integers(0, 12, (B, N))
+    cy, cx = (np.take_along_axis(c[..., k], pick, 1) + rng.normal(0, 0.03, (B, N)) for k in (0, 1))
+    h, w = rng.uniform(0.02, 0.3, (B, N)), rng.uniform(0.02, 0.3, (B, N))
+    boxes = np.clip(np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], -1), 0, 1).astype(np.float32)
+    scores = np.round(rng.uniform(0, 1, (B, N)), 3).astype(np.float32)          # rounded: equal scores occur
+    return torch.from_numpy(boxes), torch.from_numpy(scores)
+
+
+@pytest.mark.gpu
+def test_hip_nms_equals_the_tensor_formulation(monkeypatch):
+    """rope_seg_nms (librope_hip.so) keeps exactly the boxes the tensor fixed-point iteration keeps: several sets at once, padding,
+    per-class groups, limits that cut the walk short, sizes on both sides of a 64-box word."""
+    from rope_s3d_amd.maskrcnn import _nms_batched
+    rng = np.random.default_rng(11)
+    for B, N, thr, limit, with_valid, with_groups in ((3, 3000, 0.7, 1000, False, False), (2, 6000, 0.7, 1000, False, False),
+                                                       (1, 2500, 0.3, 2500, False, True), (4, 777, 0.5, 50, True, True),
+                                                       (2, 64, 0.3, 64, True, False), (1, 65, 0.7, 3, False, False), (1, 1, 0.7, 1, False, False)):
+        boxes, scores = _clustered_boxes(rng, B, N)
+        boxes, scores = boxes.cuda(), scores.cuda()
+        valid = torch.from_numpy(rng.uniform(size=(B, N)) < 0.8).cuda() if with_valid else None
+        groups = torch.from_numpy(rng.integers(0, 7, (B, N))).cuda() if with_groups else None
+        monkeypatch.setenv('ROPE_SEG_HIP', '0')
+        ref = _nms_batched(boxes, scores, thr, limit, valid=valid, groups=groups)
+        monkeypatch.setenv('ROPE_SEG_HIP', '1')
+        got = _nms_batched(boxes, scores, thr, limit, valid=valid, groups=groups)
+        assert torch.equal(ref, got), (B, N, thr, limit)
+        assert int(got.sum(1).max()) <= limit and (valid is None or not bool((got & ~valid).any()))
+
+
+@pytest.mark.gpu
+def test_hip_roi_align_equals_the_tensor_formulation(monkeypatch):
+    """rope_seg_roi_align: same pyramid level, same four taps, same bfloat16 roundings — bit for bit, for boxes inside, on the
+    edge of and beyond the map, of every pyramid level, both pool sizes."""
+    from rope_s3d_amd.maskrcnn import _pack_levels
+    rng = np.random.default_rng(5)
+    B, C = 3, 256
+    feats = [torch.from_numpy(rng.normal(0, 1, (B, C, s, s)).astype(np.float32)).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+             for s in (128, 64, 32, 16)]
+    K = 4000
+    cy, cx = rng.uniform(-0.05, 1.05, K), rng.uniform(-0.05, 1.05, K)
+    side = np.exp(rng.uniform(np.log(0.004), np.log(1.2), K))                    # sqrt(area) from below P2's to above P5's range
+    ar = np.exp(rng.uniform(-1, 1, K))
+    h, w = side * ar, side / ar
+    boxes = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 1).astype(np.float32)
+    boxes[:50] = np.clip(boxes[:50], 0, 1)
+    boxes[50:60, 2:] = boxes[50:60, :2]                                          # empty boxes
+    boxes[60:70] = [0, 0, 1, 1]
+    boxes = torch.from_numpy(boxes).cuda()
+    frame = torch.from_numpy(rng.integers(0, B, K)).cuda()
+    packed = _pack_levels(feats)
+    for pool in (7, 14):
+        monkeypatch.setenv('ROPE_SEG_HIP', '0')
+        ref = _roi_align(feats, boxes, pool, 512, frame, packed)
+        monkeypatch.setenv('ROPE_SEG_HIP', '1')
+        got = _roi_align(feats, boxes, pool, 512, frame, packed)
+        assert got.shape == ref.shape == (K, C, pool, pool)
+        same = (ref.contiguous().view(torch.int16) == got.contiguous().view(torch.int16)).flatten(1).all(1)
+        assert bool(same.all()), f"pool {pool}: {int((~same).sum())} of {K} boxes differ, first {int((~same).nonzero()[0])}"
+
+
+@pytest.mark.gpu
+def test_detections_do_not_depend_on_which_box_kernels_run(monkeypatch):
+    """Everything after the convolutional trunk (proposals, RoIAlign, heads, detection layer, masks) on the same trunk outputs of a
+    batch, with the HIP box kernels and with the tensor formulation: same classes, same scores, same masks.  (The trunk's own
+    library convolutions are not bit-reproducible from run to run, so the comparison starts behind it.)"""
+    import torch.nn.functional as F
+    from rope_s3d_amd.maskrcnn import MEAN_PIXEL
+    net = MaskRCNNSegmenter(7, device='cuda:0', seed=0, min_confidence=0.0).net
+    H, W = 90, 160
+    images = [torch.from_numpy(np.random.default_rng(i).integers(0, 255, (H, W, 3), dtype=np.uint8)).cuda() for i in range(4)]
+    scale = net.size / max(H, W)
+    nh, nw = round(H * scale), round(W * scale)
+    top, left = (net.size - nh) // 2, (net.size - nw) // 2
+    x = F.interpolate(torch.stack([im.permute(2, 0, 1) for im in images]).float(), (nh, nw), mode='bilinear', align_corners=False)
+    x = F.pad(x - torch.tensor(MEAN_PIXEL, device='cuda').view(1, 3, 1, 1), (left, net.size - nw - left, top, net.size - nh - top))
+    with torch.no_grad():
+        feats, probs, deltas = net._trunk(x.to(torch.bfloat16).contiguous())
+        out = {}
+        for flag in ('0', '1', '0'):
+            monkeypatch.setenv('ROPE_SEG_HIP', flag)
+            out.setdefault(flag, []).append(net._detect(feats, probs, deltas, H, W, scale, top, left, nh, nw))
+    for other in (out['0'][1], out['1'][0]):
+        for a, b in zip(out['0'][0], other):
+            assert len(a[0]) > 0 and all(torch.equal(p, q) for p, q in zip(a, b))
