@@ -139,6 +139,30 @@ def _build_pyramid_anchors(size: int, device) -> torch.Tensor:
     return (a - shift) / scale
 
 
+# row counts the classifier / mask head are run on are multiples of these: divisors of the usual counts (1000 proposals and up to
+# 100 detections per frame), so the usual case runs unpadded
+HEAD_ROW_STEP, MASK_ROW_STEP = 250, 50
+
+
+def _pad_rows(t: torch.Tensor, step: int) -> torch.Tensor:
+    """t with zero rows appended up to the next multiple of `step` (at least one step)."""
+    n = max(-(-len(t) // step), 1) * step
+    return t if n == len(t) else torch.cat([t, t.new_zeros((n - len(t),) + tuple(t.shape[1:]))])
+
+
+_CONSTS = {}
+
+
+def _const(values, device, dtype=None) -> torch.Tensor:
+    """torch.tensor(values, device=device) made once per (values, device, dtype): creating a tensor from host data on a GPU is a
+    blocking copy that waits for everything queued before it — a dozen of them per batch made the host and the device take turns."""
+    key = (tuple(values), str(device), dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(list(values), device=device, dtype=dtype)
+    return t
+
+
 _SEG_LIB = None
 
 
@@ -264,10 +288,10 @@ def _pack_levels(feats: List[torch.Tensor]):
     C = lv[0].shape[1]
     rows = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, C) for f in lv])
     dev = rows.device
-    Hs = torch.tensor([f.shape[2] for f in lv], device=dev)
-    Ws = torch.tensor([f.shape[3] for f in lv], device=dev)
+    Hs = _const([f.shape[2] for f in lv], dev)
+    Ws = _const([f.shape[3] for f in lv], dev)
     sizes = [f.shape[0] * f.shape[2] * f.shape[3] for f in lv]
-    offs = torch.tensor([sum(sizes[:k]) for k in range(4)], device=dev)
+    offs = _const([sum(sizes[:k]) for k in range(4)], dev)
     return rows, Hs, Ws, offs
 
 
@@ -371,18 +395,69 @@ class MaskRCNN(nn.Module):
         """Several frames of one size at once: the convolutional trunk (backbone, FPN, RPN heads — the dense contraction)
         runs on the whole batch, proposals / RoIAlign / heads / un-moulding then per frame.  Same results per frame as
         `detect` up to the batch-size dependence of the convolution algorithms the library picks."""
+        x, geo = self._mould(images)
+        feats_all, probs, deltas = self._trunk_replayed(x)
+        return self._detect(feats_all, probs, deltas, *geo)
+
+    def _mould(self, images):
+        """resize_image(mode='square') + mold_image of a batch -> (B, 3, size, size) in the weights' dtype, and the geometry to undo it."""
         dev = images[0].device
         H, W = images[0].shape[:2]
-        scale = self.size / max(H, W)                                   # resize_image(mode='square')
+        scale = self.size / max(H, W)
         nh, nw = round(H * scale), round(W * scale)
         top, left = (self.size - nh) // 2, (self.size - nw) // 2
         x = torch.stack([im.permute(2, 0, 1) for im in images]).float()
         x = F.interpolate(x, (nh, nw), mode='bilinear', align_corners=False)
-        x = x - torch.tensor(MEAN_PIXEL, device=dev).view(1, 3, 1, 1)
+        x = x - _const(MEAN_PIXEL, dev).view(1, 3, 1, 1)
         x = F.pad(x, (left, self.size - nw - left, top, self.size - nh - top))
         wdt = next(self.parameters()).dtype                              # bf16 on the GPU (cast once), f32 on CPU
-        feats_all, probs, deltas = self._trunk_replayed(x.to(wdt).contiguous())
-        return self._detect(feats_all, probs, deltas, H, W, scale, top, left, nh, nw)
+        return x.to(wdt).contiguous(), (H, W, scale, top, left, nh, nw)
+
+    @torch.no_grad()
+    def detect_batches(self, batches):
+        """`detect_batch` of every batch of an iterable, in order (a generator).  On the GPU the trunk of batch i+1 is put on a
+        second stream before the box steps of batch i start: those steps are many short launches and a few waits of the host
+        for the device, which leave the GPU idle most of the time — the next trunk runs in those gaps.  Same operations on the
+        same data as batch by batch; the trunk's outputs are copied out of the replayed graph's buffers before it runs again."""
+        it = iter(batches)
+        first = next(it, None)
+        if first is None:
+            return
+        if first[0].device.type != 'cuda':
+            yield self.detect_batch(first)
+            for b in it:
+                yield self.detect_batch(b)
+            return
+        if not hasattr(self, '_side'):
+            self._side = torch.cuda.Stream(first[0].device)
+        main = torch.cuda.current_stream(first[0].device)
+
+        def start(images):
+            x, geo = self._mould(images)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            x.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                feats, probs, deltas = self._trunk_replayed(x)
+                out = ([f.clone() for f in feats], probs.clone(), deltas.clone())
+                done = torch.cuda.Event()
+                done.record(self._side)
+            return out, geo, done
+
+        def finish(token):
+            (feats, probs, deltas), geo, done = token
+            main.wait_event(done)
+            for t in (*feats, probs, deltas):
+                t.record_stream(main)
+            return self._detect(feats, probs, deltas, *geo)
+
+        token = start(first)
+        for b in it:
+            nxt = start(b)
+            yield finish(token)
+            token = nxt
+        yield finish(token)
 
     def _trunk(self, x):
         """Backbone, FPN and the RPN heads: the static-shape, dense part -> (P2..P6, objectness (B, anchors), deltas (B, anchors, 4))."""
@@ -433,23 +508,27 @@ class MaskRCNN(nn.Module):
         of the batch together: every step works on the concatenation of the frames' boxes with a frame index beside
         them; only the final split of the masks is per frame."""
         dev, B = probs.device, probs.shape[0]
-        window = torch.tensor([top, left, top + nh, left + nw], device=dev, dtype=torch.float32)
+        window = _const([top, left, top + nh, left + nw], dev, torch.float32)
         anchors = _pyramid_anchors(self.size, dev)
         k = min(PRE_NMS_LIMIT, probs.shape[1])
         top_p, top_idx = probs.topk(k, dim=1)                               # (B, k)
-        d = deltas.gather(1, top_idx[..., None].expand(-1, -1, 4)) * torch.tensor(RPN_BBOX_STD_DEV, device=dev)
+        d = deltas.gather(1, top_idx[..., None].expand(-1, -1, 4)) * _const(RPN_BBOX_STD_DEV, dev)
         boxes = _apply_deltas(anchors[top_idx].reshape(-1, 4), d.reshape(-1, 4)).clamp(0, 1).view(B, k, 4)
         keep = _nms_batched(boxes, top_p, RPN_NMS_THRESHOLD, POST_NMS_ROIS)
         frame, pos = keep.nonzero(as_tuple=True)                            # proposals of all frames, frame-major, by anchor rank
         rois = boxes[frame, pos]
         packed = _pack_levels(feats)
-        h = self.head(_roi_align(feats, rois, POOL_SIZE, self.size, frame, packed)).flatten(1)
-        cls_prob = self.cls(h).float().softmax(-1)
-        box_delta = self.box(h).float().view(-1, self.num_classes, 4)
+        # The heads see row counts in steps (padding rows: empty boxes of frame 0, dropped again): the count of proposals that
+        # survive NMS moves by a few from batch to batch, and every new count is a new convolution shape the library has to
+        # find a kernel for first (50-200 ms the first time it meets one).
+        rois_p, frame_p = _pad_rows(rois, HEAD_ROW_STEP), _pad_rows(frame, HEAD_ROW_STEP)
+        h = self.head(_roi_align(feats, rois_p, POOL_SIZE, self.size, frame_p, packed)).flatten(1)
+        cls_prob = self.cls(h)[:len(rois)].float().softmax(-1)
+        box_delta = self.box(h)[:len(rois)].float().view(-1, self.num_classes, 4)
         cls_id = cls_prob.argmax(1)
         score = cls_prob.gather(1, cls_id[:, None])[:, 0]
-        d = box_delta[torch.arange(len(rois), device=dev), cls_id] * torch.tensor(BBOX_STD_DEV, device=dev)
-        nwin = (window - torch.tensor([0, 0, 1, 1], device=dev)) / (self.size - 1)
+        d = box_delta[torch.arange(len(rois), device=dev), cls_id] * _const(BBOX_STD_DEV, dev)
+        nwin = (window - _const([0, 0, 1, 1], dev)) / (self.size - 1)
         refined = _apply_deltas(rois, d)
         refined = torch.stack([refined[:, 0].clamp(nwin[0], nwin[2]), refined[:, 1].clamp(nwin[1], nwin[3]),
                                refined[:, 2].clamp(nwin[0], nwin[2]), refined[:, 3].clamp(nwin[1], nwin[3])], 1)
@@ -476,11 +555,12 @@ class MaskRCNN(nn.Module):
         sel = sel[first_n(frame[sel], DETECTION_MAX_INSTANCES)]
         sel = sel[frame[sel].argsort(stable=True)]                          # frame-major, best first inside a frame
         det_boxes, det_cls, det_score, det_frame = refined[sel], cls_id[sel], score[sel], frame[sel]
-        m = self.mask(_roi_align(feats, det_boxes, MASK_POOL_SIZE, self.size, det_frame, packed)).float().sigmoid()
+        m = self.mask(_roi_align(feats, _pad_rows(det_boxes, MASK_ROW_STEP), MASK_POOL_SIZE, self.size, _pad_rows(det_frame, MASK_ROW_STEP),
+                                 packed))[:len(sel)].float().sigmoid()
         m = m[torch.arange(len(sel), device=dev), det_cls]                  # (K, 28, 28) of each detection's class
         # un-mould: boxes back to original image pixels, masks resized into their box (utils.unmold_mask)
-        px = det_boxes * (self.size - 1) + torch.tensor([0, 0, 1, 1], device=dev)
-        px = ((px - torch.tensor([top, left, top, left], device=dev)) / scale).round().long()
+        px = det_boxes * (self.size - 1) + _const([0, 0, 1, 1], dev)
+        px = ((px - _const([top, left, top, left], dev)) / scale).round().long()
         # every detection's 28x28 mask is resized into its (clipped) box — all of them in one sampling pass over the
         # image grid: pixel centre (Y+0.5, X+0.5) of box [y1,y2)x[x1,x2) looks up the mask at ((Y+0.5-y1)/(y2-y1), ...),
         # which is the bilinear resize with half-pixel centres and edge clamping that the per-box resize computes
@@ -613,6 +693,8 @@ class MaskRCNNSegmenter:
             self.net.load_state_dict(state_dict)
         self.net = _fold_batchnorm(self.net.eval()).to(self.device)
         if self.device.type == 'cuda':                                   # weights to bf16 once: MFMA path of MIOpen / hipBLASLt
+            from .utils import limit_host_threads
+            limit_host_threads()                                           # see there: idle pool threads spinning freeze the process under a CPU quota
             self.net = self.net.to(torch.bfloat16)
             for part in (self.net.fpn, self.net.rpn):                      # see detect_batch for the layouts
                 part.to(memory_format=torch.channels_last)
@@ -622,9 +704,20 @@ class MaskRCNNSegmenter:
 
     def batch(self, frames) -> list:
         """Several frames of one size in one pass of the convolutional trunk -> list of result dicts."""
-        rgb = [torch.from_numpy(np.ascontiguousarray(f[..., ::-1])).to(self.device) for f in frames]
-        return [{'class_ids': cls.numpy(), 'scores': score.numpy(), 'masks': masks.numpy()}
-                for cls, score, masks in self.net.detect_batch(rgb)]
+        return self._results(self.net.detect_batch(self._upload(frames)))
+
+    def batches(self, groups):
+        """`batch` of every group of frames of an iterable, in order (a generator); on the GPU the next group's trunk overlaps
+        the current group's box steps (MaskRCNN.detect_batches)."""
+        for out in self.net.detect_batches(self._upload(g) for g in groups):
+            yield self._results(out)
+
+    def _upload(self, frames):
+        return [torch.from_numpy(np.ascontiguousarray(f[..., ::-1])).to(self.device) for f in frames]
+
+    @staticmethod
+    def _results(out):
+        return [{'class_ids': cls.numpy(), 'scores': score.numpy(), 'masks': masks.numpy()} for cls, score, masks in out]
 
 
 class BatchAheadSegmenter:
@@ -662,14 +755,15 @@ class BatchAheadSegmenter:
 
     def _work(self, frames, keys):
         try:
-            for i in range(0, len(frames), self._batch):
-                with self._seg_lock:
-                    results = self._seg.batch(frames[i:i + self._batch])
-                with self._cv:
-                    for k, r in zip(keys[i:i + self._batch], results):
-                        self._store.setdefault(k, []).append(r)
-                        self._pending[k] -= 1
-                    self._cv.notify_all()
+            groups = [frames[i:i + self._batch] for i in range(0, len(frames), self._batch)]
+            with self._seg_lock:                          # for the whole chunk: the next group's trunk is in flight between results
+                for n, results in enumerate(self._seg.batches(groups)):
+                    i = n * self._batch
+                    with self._cv:
+                        for k, r in zip(keys[i:i + self._batch], results):
+                            self._store.setdefault(k, []).append(r)
+                            self._pending[k] -= 1
+                        self._cv.notify_all()
         except BaseException as e:                        # noqa: BLE001 — handed to the consumer, which re-raises it
             with self._cv:
                 self._error = e

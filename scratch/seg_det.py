@@ -23,4 +23,8 @@ with torch.no_grad():
     def same(a, b):
         return [all(torch.equal(p, q) for p, q in zip(x_, y_)) for x_, y_ in zip(a, b)]
     r1, r2, g1, g2 = run('0'), run('0'), run('1'), run('1')
+    import rope_s3d_amd.maskrcnn as M
+    M.HEAD_ROW_STEP = 1; M.MASK_ROW_STEP = 1
+    u1, u2, v1 = run('0'), run('0'), run('1')
+    print('unpadded: ref vs ref', same(u1, u2), 'ref vs hip', same(u1, v1), 'padded vs unpadded', same(r1, u1))
 print('ref vs ref', same(r1, r2)); print('hip vs hip', same(g1, g2)); print('ref vs hip', same(r1, g1))

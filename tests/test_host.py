@@ -522,3 +522,19 @@ def test_target_packing_native_numpy_and_oracle_agree():
     assert np.array_equal(got & np.uint64((1 << 40) - 1), np.minimum(q, 2.0 ** 39 - 1).astype(np.uint64))
     assert got[0, 0] == np.uint64(bits[0, 0]) << np.uint64(40) and (got[1, :3] & np.uint64(0xFF)).tolist() == [0, 2, 2]   # halves to even
     assert int(got[0, 5]) & ((1 << 40) - 1) == 2 ** 39 - 1                                      # 200 m clips
+
+
+def test_cpu_budget_and_thread_cap(monkeypatch):
+    """cpu_budget: affinity cut to the cgroup quota; limit_host_threads caps torch's pool by it (ROPE_TORCH_THREADS overrides)."""
+    import torch
+    from rope_s3d_amd.utils import cpu_budget, limit_host_threads
+    n = cpu_budget()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        got = limit_host_threads(most=2)
+        assert got == torch.get_num_threads() <= max(2, 1) and got <= before
+        monkeypatch.setenv('ROPE_TORCH_THREADS', '3')
+        assert limit_host_threads() == 3
+    finally:
+        torch.set_num_threads(before)

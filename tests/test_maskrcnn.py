@@ -341,7 +341,12 @@ def test_detections_do_not_depend_on_which_box_kernels_run(monkeypatch):
     batch, with the HIP box kernels and with the tensor formulation: same classes, same scores, same masks.  (The trunk's own
     library convolutions are not bit-reproducible from run to run, so the comparison starts behind it.)"""
     import torch.nn.functional as F
+    from rope_s3d_amd import maskrcnn as M
     from rope_s3d_amd.maskrcnn import MEAN_PIXEL
+    # no padding of the heads' row counts here: a padded count is another convolution shape, and the library's kernel for it
+    # may add its partial sums in a different order every run (seen with 8192 rows) — the comparison needs a repeatable head
+    monkeypatch.setattr(M, 'HEAD_ROW_STEP', 1)
+    monkeypatch.setattr(M, 'MASK_ROW_STEP', 1)
     net = MaskRCNNSegmenter(7, device='cuda:0', seed=0, min_confidence=0.0).net
     H, W = 90, 160
     images = [torch.from_numpy(np.random.default_rng(i).integers(0, 255, (H, W, 3), dtype=np.uint8)).cuda() for i in range(4)]
@@ -359,3 +364,58 @@ def test_detections_do_not_depend_on_which_box_kernels_run(monkeypatch):
     for other in (out['0'][1], out['1'][0]):
         for a, b in zip(out['0'][0], other):
             assert len(a[0]) > 0 and all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_pipelined_batches_give_the_batch_by_batch_results(monkeypatch):
+    """MaskRCNNSegmenter.batches overlaps the next group's trunk (second stream) with the current group's box steps.  With the
+    trunk's outputs fixed per input (its library convolutions are not bit-reproducible run to run) every group's classes,
+    scores and masks equal those of `batch` on the group alone — whichever stream produced and copied the trunk outputs."""
+    from rope_s3d_amd import maskrcnn as M
+    monkeypatch.setattr(M, 'HEAD_ROW_STEP', 1)          # see test_detections_do_not_depend_on_which_box_kernels_run
+    monkeypatch.setattr(M, 'MASK_ROW_STEP', 1)
+    seg = MaskRCNNSegmenter(7, device='cuda:0', seed=0, min_confidence=0.0)
+    net = seg.net
+    groups = [[np.random.default_rng(10 * g + i).integers(0, 255, (90, 160, 3), dtype=np.uint8) for i in range(4)] for g in range(4)]
+    real, cache = net._trunk_replayed, {}
+
+    def fixed_trunk(x):
+        key = float(x.float().sum())
+        if key not in cache:
+            feats, probs, deltas = real(x)
+            cache[key] = ([f.clone() for f in feats], probs.clone(), deltas.clone())
+        return cache[key]
+    net._trunk_replayed = fixed_trunk
+    try:
+        alone = [seg.batch(g) for g in groups]
+        piped = list(seg.batches(groups))
+        assert len(cache) == len(groups)
+    finally:
+        net._trunk_replayed = real
+    assert len(piped) == len(groups)
+    for a, b in zip(alone, piped):
+        assert len(a) == len(b) == 4
+        for ra, rb_ in zip(a, b):
+            assert len(ra['class_ids']) > 0 and all(np.array_equal(ra[k], rb_[k]) for k in ra)
+    # and with the real trunk: same structure (the values are those of a different run of the convolutions)
+    for res in seg.batches(groups[:2]):
+        assert len(res) == 4 and all(r['masks'].shape[:2] == (90, 160) for r in res)
+
+
+def test_heads_run_on_row_counts_in_steps():
+    """_pad_rows: the classifier and mask heads see multiples of a step (a new row count is a new convolution shape for the
+    library); padding rows are empty boxes whose results are dropped — same detections as without padding (CPU float32)."""
+    from rope_s3d_amd import maskrcnn as M
+    assert M._pad_rows(torch.ones(7, 4), 5).shape == (10, 4) and M._pad_rows(torch.ones(10, 4), 5).shape == (10, 4)
+    assert M._pad_rows(torch.ones(0, 4), 5).shape == (5, 4) and float(M._pad_rows(torch.ones(7, 4), 5)[7:].abs().sum()) == 0
+    seg = MaskRCNNSegmenter(7, device='cpu', seed=0, min_confidence=0.0)
+    frame = np.random.default_rng(2).integers(0, 255, (45, 80, 3), dtype=np.uint8)
+    padded = seg(frame)
+    old = M.HEAD_ROW_STEP, M.MASK_ROW_STEP
+    M.HEAD_ROW_STEP, M.MASK_ROW_STEP = 1, 1
+    try:
+        plain = seg(frame)
+    finally:
+        M.HEAD_ROW_STEP, M.MASK_ROW_STEP = old
+    assert np.array_equal(padded['class_ids'], plain['class_ids']) and np.allclose(padded['scores'], plain['scores'], atol=1e-5)
+    assert (padded['masks'] != plain['masks']).mean() < 1e-3

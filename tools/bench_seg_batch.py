@@ -18,3 +18,10 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"batch of 8 frames 160x90: {dt * 1e3:.1f} ms = {dt / 8 * 1e3:.2f} ms/frame = {8 / dt:.1f} frames/s")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in seg.batches([frames] * n):                      # the next group's trunk on a second stream beside this group's box steps
+    pass
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"the same through batches(): {dt * 1e3:.1f} ms = {dt / 8 * 1e3:.2f} ms/frame = {8 / dt:.1f} frames/s")
