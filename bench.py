@@ -99,8 +99,10 @@ def self_launch(args):
 def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None, loss=0, flags=None):
     """The CPU oracle (C restatement of the reference path) on this host's cores, bounded sample."""
     from oracle import oracle as orc
-    # the GPU box exposes every host core but a 1-GPU job's share is 16 (gpurun process guard)
-    threads = min(len(os.sched_getaffinity(0)), 16)
+    # the GPU box shows every host core but a 1-GPU job's share is a cgroup quota of 16 CPUs: more threads than that are
+    # throttled by the scheduler, not faster
+    from rope_s3d_amd.utils import cpu_budget
+    threads = min(cpu_budget(), 16)
     o = orc.Oracle(robot.verts, robot.faces, robot.vtx_off, robot.tri_off, robot.joint_fixed, robot.joint_axes,
                    PV, W, H, znear, zfar)
     sample = np.ascontiguousarray(cand[:n_sample])

@@ -62,7 +62,8 @@ def run(args):
                    do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
     # Frames are independent, and one frame's ~25 short dependent batches leave the GPU idle between them: k Predictors
     # (own context and stream each) fed by k threads fill those gaps (prediction/pool.py).  Not with a segmenter that keeps
-    # per-chunk state or a network on the GPU: that stage is the bottleneck then, and it is not written for several threads.
+    # per-chunk state or a network on the GPU: with the network's thread beside them, 2 / 4 / 8 Predictors sharing one
+    # batch-ahead segmenter were slower than one (195-232 against 249 frames/s, tools/bench_pipeline.py).
     n_pred = max(1, int(getattr(args, 'predictors', 1) or 1))
     pool = None
     if n_pred > 1 and am.synthetic:
