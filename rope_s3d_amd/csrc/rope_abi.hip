@@ -92,6 +92,7 @@ struct rope_ctx {
     // MODE_SPLIT: busy workgroups aimed at per launch (one generation: 2 per CU), fewest / most per (tile, candidate), and the
     // workgroups per launch of the scoring pass that follows.  Measured at 160x90, 640x360 and 640x480 (tools/r02_split_tune.sh).
     int split_target = 512, split_min = 8, split_min_many = 3, split_cap = 64, score_target = 6144;
+    int layer_min_wg = 64;                 // fewest busy workgroups of a shared-layer launch for it to pay in a small batch (layers_pay)
     int strategy = 0;                          // STRATEGY_* bits (rope_set_strategy): launch structure only, never a result
     // large batches: queue of the (candidate, tile) pairs with something to draw, worked off by a grid that just fills the chip
     uint32_t *d_qitems = nullptr;
@@ -177,6 +178,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
     if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 31;                     // tuning aid: rope_set_strategy's bits
     if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN")) c->split_min = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("ROPE_LAYER_MIN_WG")) c->layer_min_wg = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN_MANY")) c->split_min_many = std::max(1, std::min(64, std::atoi(e)));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
@@ -605,6 +607,15 @@ static int ensure_empty(rope_ctx *c, int loss, const FrameParams &fp)
 // Layers pay off when many candidates share one upstream pose (lookup grids, sweeps of U).
 static bool want_layers(const rope_ctx *c) { return c->n_layers * 4 <= c->C; }
 
+// A small batch whose candidates share one or two upstream poses (a sweep of the third joint) would draw links 0-2 in a layer
+// launch of a handful of workgroups — 59 000 triangles each, the rest of the chip idle (100 us at 160x90) — before the scoring
+// launch: the split path draws all six links per candidate over many workgroups instead and is more than twice as fast there.
+static bool layers_pay(const rope_ctx *c)
+{
+    const int busy_tiles = std::max(std::min(2, c->n_tiles), c->n_tiles / 3);
+    return c->C > 256 || c->n_layers * busy_tiles >= c->layer_min_wg;
+}
+
 static int ensure_layers(rope_ctx *c)
 {
     size_t need = (size_t)c->n_layers * c->n_tiles * (TILE_W * TILE_H);
@@ -671,7 +682,7 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
                         hipEvent_t *ev /* 5 events or nullptr */, bool views = false)
 {
-    const bool layers = !views && want_layers(c) && !(c->strategy & STRATEGY_NO_LAYERS);
+    const bool layers = !views && want_layers(c) && layers_pay(c) && !(c->strategy & STRATEGY_NO_LAYERS);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
