@@ -100,9 +100,16 @@ struct rope_ctx {
     int n_cu = 256;
 
     // stored lookup table (cropped sqrt-depth of a pose grid)
-    float *d_table = nullptr;
+    float *d_table = nullptr;                  // dense rows while a table is built (freed once it is packed)
     size_t table_cap = 0;
+    // the stored table: per row the rectangle that holds its samples, its values in d_tpack at d_toff (rope_lookup_build)
+    ushort4 *d_trect = nullptr;
+    unsigned long long *d_toff = nullptr, *d_tused = nullptr;
+    float *d_tpack = nullptr;
+    uint64_t *d_ttotal = nullptr;
+    size_t trow_cap = 0;
     int table_C = 0, table_crop[4] = {0, 0, 0, 0};
+    size_t table_floats = 0;                   // floats the packed table holds
     uint64_t *d_zero_total = nullptr;
     // scores of the table's rows: buffers of their own (a grid may hold more rows than one candidate batch)
     uint64_t *d_tsums = nullptr;
@@ -237,7 +244,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_qctr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_qctr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -918,6 +925,30 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
         HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a, use_clip(c)));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    // keep of every row only the rectangle that holds its samples (the crop is the box of all poses together), then let the
+    // dense rows go: the table is read once per frame from end to end, and this is what that pass streams
+    if ((size_t)C > c->trow_cap) {
+        c->trow_cap = 0;
+        HIP_TRY(c, realloc_dev(&c->d_trect, (size_t)C));
+        HIP_TRY(c, realloc_dev(&c->d_toff, (size_t)C));
+        c->trow_cap = (size_t)C;
+    }
+    if (!c->d_tused) HIP_TRY(c, realloc_dev(&c->d_tused, (size_t)1));
+    if (!c->d_ttotal) HIP_TRY(c, realloc_dev(&c->d_ttotal, (size_t)ROPE_SUM_WORDS));
+    float *all = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&all, (need + 4 * (size_t)C) * sizeof(float)));
+    unsigned long long used = 0;
+    hipError_t e = hipMemsetAsync(c->d_tused, 0, sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_table_pack(c->stream, crop[3] - crop[2] + 1, crop[1] - crop[0] + 1, c->d_table, C, c->d_trect, c->d_toff, c->d_tused, all);
+    if (e == hipSuccess) e = hipMemcpyAsync(&used, c->d_tused, sizeof(used), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (c->d_tpack) { (void)hipFree(c->d_tpack); c->d_tpack = nullptr; }
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tpack, std::max<size_t>(used, 4) * sizeof(float));
+    if (e == hipSuccess && used) e = hipMemcpy(c->d_tpack, all, used * sizeof(float), hipMemcpyDeviceToDevice);
+    (void)hipFree(all);
+    (void)hipFree(c->d_table); c->d_table = nullptr; c->table_cap = 0;
+    HIP_TRY(c, e);
+    c->table_floats = used;
     c->table_C = C;
     std::memcpy(c->table_crop, crop, 4 * sizeof(int32_t));
     return ROPE_OK;
@@ -932,7 +963,8 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
-    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_table, c->table_C, c->d_t32, c->d_depth /* scratch: H x W floats */, c->d_tsums));
+    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_trect, c->d_toff, c->d_tpack, c->table_C, c->d_t32, c->d_depth /* scratch: H x W floats */,
+                                  c->d_ttotal, c->d_tsums));
     HIP_TRY(c, launch_finalize(c->stream, c->d_tsums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_terr));
     if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_terr, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     double tail[2];

@@ -141,10 +141,14 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
                         uint64_t *empty_sums, uint64_t *total);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err /* C + 2: errors, best error, best index */);
+// the stored lookup table keeps of every row the rectangle that holds its samples: dense rows (C x ch x cw) -> rects / offs /
+// packed (values of row k at packed + offs[k], a multiple of four floats); *used = floats taken in packed (zero it first)
+hipError_t launch_table_pack(hipStream_t st, int cw, int ch, const float *table, int C, ushort4 *rects, unsigned long long *offs,
+                             unsigned long long *used, float *packed);
 // score every row of a stored lookup table against the float32 target plane
-// t32c: scratch of crop_h x crop_w floats (the cropped target, rebuilt by every call)
-hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, float *t32c,
-                              uint64_t *sums);
+// t32c: scratch of crop_h x crop_w floats (the cropped target, rebuilt by every call); total: ROPE_SUM_WORDS words of scratch
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
+                              const float *packed, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums);
 hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);
 
 }  // namespace rope

@@ -1305,41 +1305,29 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
 }
 
 // ------------------------------------------------------------- lookup table -----
-// Lookup stage against a stored table (predict.py:165-171): per row k of the table,
-// the exact sums of |T - sqrtD_k| in Q32 over the crop.  Pure streaming: N*h*w*4 bytes read once.
-// the crop of the target plane as one contiguous row, laid out like a row of the table (no index arithmetic per sample later)
-__global__ void __launch_bounds__(256)
-crop_target_kernel(FrameParams fp, const float *__restrict__ t32, float *__restrict__ t32c)
-{
-    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c < cw && r < ch) t32c[(size_t)r * cw + c] = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
-}
+// Lookup stage against a stored table (predict.py:165-171): per row k of the table, the exact sums of |T - sqrtD_k| in Q32
+// over the crop.  The crop is the box of every pose of the grid; one pose covers a fraction of it, and where a row holds
+// nothing the term is |T - 0|, the same for every row.  So a row is stored as the rectangle that holds its samples
+// (table_pack_kernel), the sums of |T| over the whole crop are taken once per frame (crop_total_kernel), and a row's sums are
+// total + sum over its rectangle of (|T - D| - |T|) — integers, so exactly the sums over the whole crop.
 
-__global__ void __launch_bounds__(256)
-table_score_kernel(FrameParams fp, const float *__restrict__ table, const float *__restrict__ t32c, uint64_t *__restrict__ sums)
+// One workgroup: the crop of the target plane as one contiguous array laid out like the crop (no index arithmetic on the
+// image per sample later), and the sums of |T| over it.
+__global__ void __launch_bounds__(1024)
+crop_total_kernel(FrameParams fp, const float *__restrict__ t32, float *__restrict__ t32c, uint64_t *__restrict__ total /* ROPE_SUM_WORDS */)
 {
     __shared__ uint64_t lds[4];
     const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1, n = cw * ch;
-    const float *row = table + (size_t)blockIdx.x * n;
     if (threadIdx.x < 4) lds[threadIdx.x] = 0;
     __syncthreads();
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
-    auto one = [&](int i, float d) {
-        acc_sq<false>(s, q32_of_f32(fabsf(t32c[i] - d)));       // a zero difference adds zeros: no branch
-    };
-    // 16-byte loads where the row start allows it (rows are n floats apart, so alignment depends on the row)
-    const int head = (int)((4 - (((size_t)blockIdx.x * n) & 3)) & 3);
-    for (int i = threadIdx.x; i < head && i < n; i += blockDim.x) one(i, row[i]);
-    const int n4 = (n - head) >> 2;
-    const float4 *row4 = reinterpret_cast<const float4 *>(row + head);
-    for (int i4 = threadIdx.x; i4 < n4; i4 += blockDim.x) {
-        const float4 d = row4[i4];
-        const int i = head + 4 * i4;
-        one(i, d.x); one(i + 1, d.y); one(i + 2, d.z); one(i + 3, d.w);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i / cw, c = i - r * cw;
+        const float t = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
+        t32c[i] = t;
+        acc_sq<false>(s, q32_of_f32(fabsf(t - 0.0f)));
     }
-    for (int i = head + 4 * n4 + threadIdx.x; i < n; i += blockDim.x) one(i, row[i]);
     const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1352,6 +1340,83 @@ table_score_kernel(FrameParams fp, const float *__restrict__ table, const float 
     if (threadIdx.x < ROPE_SUM_WORDS) {
         uint64_t v = 0;
         for (int k = 0; k < 4; k++) if ((int)threadIdx.x == words[k]) v = lds[k];
+        total[threadIdx.x] = v;
+    }
+}
+
+// Build time: the rectangle of dense row k that holds anything, copied to packed[] at an offset reserved with one atomic (a
+// multiple of four floats: 16-byte loads later).  rects[k] = (first row, first column, rows, columns) inside the crop.
+__global__ void __launch_bounds__(256)
+table_pack_kernel(int cw, int ch, const float *__restrict__ table, ushort4 *__restrict__ rects, unsigned long long *__restrict__ offs,
+                  unsigned long long *__restrict__ used, float *__restrict__ packed)
+{
+    __shared__ int s_box[4];
+    __shared__ unsigned long long s_off;
+    const int n = cw * ch;
+    const float *row = table + (size_t)blockIdx.x * n;
+    if (threadIdx.x == 0) { s_box[0] = ch; s_box[1] = -1; s_box[2] = cw; s_box[3] = -1; }
+    __syncthreads();
+    int r0 = ch, r1 = -1, c0 = cw, c1 = -1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (row[i] != 0.0f) {
+            const int r = i / cw, c = i - r * cw;
+            r0 = min(r0, r); r1 = max(r1, r); c0 = min(c0, c); c1 = max(c1, c);
+        }
+    if (r1 >= 0) { atomicMin(&s_box[0], r0); atomicMax(&s_box[1], r1); atomicMin(&s_box[2], c0); atomicMax(&s_box[3], c1); }
+    __syncthreads();
+    r0 = s_box[0]; r1 = s_box[1]; c0 = s_box[2]; c1 = s_box[3];
+    const int h = r1 >= r0 ? r1 - r0 + 1 : 0, w = h ? c1 - c0 + 1 : 0, m = h * w;
+    if (threadIdx.x == 0) {
+        s_off = m ? atomicAdd(used, (unsigned long long)((m + 3) & ~3)) : 0ull;
+        rects[blockIdx.x] = make_ushort4((unsigned short)(h ? r0 : 0), (unsigned short)(h ? c0 : 0), (unsigned short)h, (unsigned short)w);
+        offs[blockIdx.x] = s_off;
+    }
+    __syncthreads();
+    float *dst = packed + s_off;
+    for (int i = threadIdx.x; i < ((m + 3) & ~3); i += blockDim.x) {
+        const int r = i / max(w, 1), c = i - r * w;
+        dst[i] = i < m ? row[(size_t)(r0 + r) * cw + c0 + c] : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned long long *__restrict__ offs, const float *__restrict__ packed,
+                   const float *__restrict__ t32c, const uint64_t *__restrict__ total, uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t lds[4];
+    const ushort4 rc = rects[blockIdx.x];
+    const int r0 = rc.x, c0 = rc.y, w = rc.w, m = (int)rc.z * (int)rc.w;
+    const float4 *row4 = reinterpret_cast<const float4 *>(packed + offs[blockIdx.x]);
+    if (threadIdx.x < 4) lds[threadIdx.x] = 0;
+    __syncthreads();
+    // s = sum over the rectangle of |T - D| minus sum of |T|, modulo 2^64 (the true value of total + s is not negative)
+    uint64_t s[ROPE_SUM_WORDS];
+    s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
+    const float inv_w = 1.0f / (float)max(w, 1);
+    auto one = [&](int i, float d) {
+        if (i >= m) return;
+        // i / w for i < 2^14, w < 2^11: (i + 0.5) / w is at least 0.5 / w away from an integer, the product's error far less
+        const int r = (int)(((float)i + 0.5f) * inv_w), c = i - r * w;
+        const float t = t32c[(r0 + r) * cw + c0 + c];
+        acc_sq<false>(s, q32_of_f32(fabsf(t - d)));
+        acc_sq<true>(s, q32_of_f32(fabsf(t - 0.0f)));
+    };
+    for (int i4 = threadIdx.x; 4 * i4 < m; i4 += blockDim.x) {
+        const float4 d = row4[i4];
+        one(4 * i4, d.x); one(4 * i4 + 1, d.y); one(4 * i4 + 2, d.z); one(4 * i4 + 3, d.w);
+    }
+    const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t v = s[words[k]];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds[k], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (threadIdx.x < ROPE_SUM_WORDS) {
+        uint64_t v = 0;
+        for (int k = 0; k < 4; k++) if ((int)threadIdx.x == words[k]) v = total[words[k]] + lds[k];
         sums[(size_t)blockIdx.x * ROPE_SUM_WORDS + threadIdx.x] = v;
     }
 }
@@ -1578,12 +1643,18 @@ hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total
     return hipGetLastError();
 }
 
-hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const float *table, int C, const float *t32, float *t32c,
-                              uint64_t *sums)
+hipError_t launch_table_pack(hipStream_t st, int cw, int ch, const float *table, int C, ushort4 *rects, unsigned long long *offs,
+                             unsigned long long *used, float *packed)
 {
-    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
-    hipLaunchKernelGGL(crop_target_kernel, dim3((cw + 255) / 256, ch), dim3(256), 0, st, fp, t32, t32c);
-    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, fp, table, t32c, sums);
+    hipLaunchKernelGGL(table_pack_kernel, dim3(C), dim3(256), 0, st, cw, ch, table, rects, offs, used, packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
+                              const float *packed, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums)
+{
+    hipLaunchKernelGGL(crop_total_kernel, dim3(1), dim3(1024), 0, st, fp, t32, t32c, total);
+    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, fp.c1 - fp.c0 + 1, rects, offs, packed, t32c, total, sums);
     return hipGetLastError();
 }
 
