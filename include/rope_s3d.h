@@ -243,6 +243,12 @@ int rope_set_strategy(rope_ctx *ctx, int flags);
  *   level_hw        4 x (H, W) int32;  level_off 4 int64
  *   inv_level_unit  1 / (224 / image_size) as float32;  t: `pool` float32 sample positions in [0, 1] (device)
  *   out_bf16        n_boxes x pool x pool x channels bfloat16 */
+/* rope_seg_bias_act: what follows a convolution, in place and in one pass: y <- [relu](bf16(bf16(y + bias[channel]) [+ residual])),
+ * with the roundings separate tensor operations would make.
+ *   y_bf16    n bfloat16 (n a multiple of 8), NCHW (`inner` = H*W, a multiple of 8) or channels-last (`inner` = 1, channels a
+ *             multiple of 8);  bias_bf16: `channels` bfloat16;  residual_bf16: n bfloat16 in y's layout, or NULL;  relu: 0 / 1 */
+int rope_seg_bias_act(void *y_bf16, const void *bias_bf16, const void *residual_bf16, int64_t n, int channels, int64_t inner, int relu,
+                      void *stream);
 int rope_seg_nms(const float *boxes, const int32_t *groups, const uint8_t *valid, int n_sets, int n, float iou_thr, int limit,
                  uint64_t *scratch, uint8_t *keep, void *stream);
 int rope_seg_roi_align(const void *rows_bf16, const float *boxes, const int32_t *frame, const int32_t *level_hw,

@@ -190,7 +190,56 @@ roi_align_kernel(const uint16_t *__restrict__ rows, const float4 *__restrict__ b
     }
 }
 
+// ------------------------------------------------- bias / residual / ReLU -----
+// What follows a library convolution in the trunk, in one pass over its output instead of up to four (bias add, residual add,
+// ReLU as separate tensor operations): y <- [relu]( bf16( bf16(y + bias[channel]) [+ residual] ) ), the roundings of the separate
+// operations kept.  Eight bfloat16 per lane (16 bytes).  chan_inner = H*W/8 for NCHW (eight neighbours share a channel),
+// 0 for channels-last (the eight are channels c .. c+7).
+__global__ void __launch_bounds__(256)
+bias_act_kernel(uint16_t *__restrict__ y, const uint16_t *__restrict__ bias, const uint16_t *__restrict__ res, long long n8, int channels,
+                int chan_inner, int relu)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    uint4 v = reinterpret_cast<uint4 *>(y)[i];
+    uint32_t w[4] = {v.x, v.y, v.z, v.w}, r[4] = {0, 0, 0, 0}, b[4];
+    if (chan_inner) {
+        const uint32_t bb = bias[(i / chan_inner) % channels];
+        b[0] = b[1] = b[2] = b[3] = bb | (bb << 16);
+    } else {
+        const uint4 bv = *reinterpret_cast<const uint4 *>(bias + (i * 8) % channels);
+        b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+    }
+    if (res) { const uint4 rv = reinterpret_cast<const uint4 *>(res)[i]; r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int sh = 16 * h;
+            float f = badd(bf2f((uint16_t)(w[q] >> sh)), bf2f((uint16_t)(b[q] >> sh)));
+            if (res) f = badd(f, bf2f((uint16_t)(r[q] >> sh)));
+            if (relu) f = f > 0.0f ? f : 0.0f;             // relu(NaN) stays out of it: activations are finite
+            out |= (uint32_t)f2bf(f) << sh;
+        }
+        w[q] = out;
+    }
+    reinterpret_cast<uint4 *>(y)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 }  // namespace
+
+extern "C" int rope_seg_bias_act(void *y_bf16, const void *bias_bf16, const void *residual_bf16, int64_t n, int channels, int64_t inner,
+                                 int relu, void *stream)
+{
+    if (!y_bf16 || !bias_bf16 || n < 8 || (n & 7) || channels < 1) return ROPE_E_ARG;
+    if (inner > 1 ? (inner & 7) != 0 : (channels & 7) != 0) return ROPE_E_ARG;   // eight neighbours share a channel, or are eight channels
+    const long long n8 = n / 8;
+    hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint16_t *>(y_bf16),
+                       reinterpret_cast<const uint16_t *>(bias_bf16), reinterpret_cast<const uint16_t *>(residual_bf16), n8, channels,
+                       inner > 1 ? (int)(inner / 8) : 0, relu);
+    return hipGetLastError() == hipSuccess ? ROPE_OK : ROPE_E_HIP;
+}
 
 extern "C" int rope_seg_nms(const float *boxes, const int32_t *groups, const uint8_t *valid, int n_sets, int n, float iou_thr,
                             int limit, uint64_t *scratch, uint8_t *keep, void *stream)

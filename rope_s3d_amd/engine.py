@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_set_strategy',
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
-    'rope_seg_nms', 'rope_seg_roi_align')
+    'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP = 0, 1, 2, 3
@@ -96,6 +96,7 @@ def load_library(path: str = None):
     lib.rope_downsample_even.argtypes = [vp, i32, i32, i32, C.c_int64, i32, i32, vp]
     lib.rope_seg_nms.argtypes = [vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp]
     lib.rope_seg_roi_align.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp]
+    lib.rope_seg_bias_act.argtypes = [vp, vp, vp, C.c_int64, i32, C.c_int64, i32, vp]
     lib.rope_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
     _lib = lib

@@ -52,6 +52,9 @@ class _Bottleneck(nn.Module):
         self.short = nn.Sequential(nn.Conv2d(cin, mid * 4, 1, stride), _bn(mid * 4)) if project else None
 
     def forward(self, x):
+        if isinstance(self.b1, nn.Identity) and _fusable(x):      # batch norms folded, bf16 on the GPU: one pass after every convolution
+            y = _conv_act(self.c2, _conv_act(self.c1, x))
+            return _conv_act(self.c3, y, res=x if self.short is None else self.short(x))
         y = F.relu(self.b1(self.c1(x)))
         y = F.relu(self.b2(self.c2(y)))
         y = self.b3(self.c3(y))
@@ -104,7 +107,7 @@ class _RPN(nn.Module):
         self.cls, self.box = nn.Conv2d(512, 2 * a, 1), nn.Conv2d(512, 4 * a, 1)
 
     def forward(self, p):
-        h = F.relu(self.shared(p))
+        h = _conv_act(self.shared, p) if _fusable(p) else F.relu(self.shared(p))
         logits = self.cls(h).permute(0, 2, 3, 1).reshape(p.shape[0], -1, 2)
         deltas = self.box(h).permute(0, 2, 3, 1).reshape(p.shape[0], -1, 4)
         return logits.float().softmax(-1)[..., 1], deltas.float()
@@ -180,6 +183,38 @@ def _seg_kernels(t: torch.Tensor) -> bool:
     """The HIP kernels serve tensors on the GPU; ROPE_SEG_HIP=0 keeps the tensor formulation there too (equality tests, timing)."""
     import os
     return t.is_cuda and os.environ.get('ROPE_SEG_HIP', '1') != '0'
+
+
+def _fusable(x: torch.Tensor) -> bool:
+    return x.dtype == torch.bfloat16 and _seg_kernels(x)
+
+
+def _conv_act(conv: nn.Conv2d, x: torch.Tensor, res: torch.Tensor = None, relu: bool = True) -> torch.Tensor:
+    """relu(conv(x) + bias [+ res]) with everything after the library convolution in ONE pass over its output (rope_seg_bias_act,
+    in place) instead of a bias pass, an addition and a ReLU — the same roundings to bfloat16 as those separate operations."""
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    n, c, hw = y.numel(), y.shape[1], y.shape[2] * y.shape[3]
+    if y.is_contiguous() and hw % 8 == 0:
+        inner = hw
+    elif y.is_contiguous(memory_format=torch.channels_last) and c % 8 == 0:
+        inner = 1
+    else:
+        inner = 0
+    if res is not None and (res.shape != y.shape or res.stride() != y.stride()):
+        res = res.contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format) if inner else res
+        if inner and res.stride() != y.stride():
+            inner = 0
+    if inner == 0 or conv.bias is None or n % 8:
+        if conv.bias is not None:
+            y = y + conv.bias.view(1, -1, 1, 1)
+        if res is not None:
+            y = y + res
+        return F.relu(y) if relu else y
+    rc = _seg_lib().rope_seg_bias_act(y.data_ptr(), conv.bias.data_ptr(), None if res is None else res.data_ptr(), n, c, inner, int(relu),
+                                      torch.cuda.current_stream(y.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"rope_seg_bias_act failed ({rc})")
+    return y
 
 
 def _apply_deltas(boxes, deltas):

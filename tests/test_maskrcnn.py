@@ -419,3 +419,31 @@ def test_heads_run_on_row_counts_in_steps():
         M.HEAD_ROW_STEP, M.MASK_ROW_STEP = old
     assert np.array_equal(padded['class_ids'], plain['class_ids']) and np.allclose(padded['scores'], plain['scores'], atol=1e-5)
     assert (padded['masks'] != plain['masks']).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_bias_act_equals_the_separate_tensor_operations(monkeypatch):
+    """rope_seg_bias_act after a convolution: bias, residual and ReLU in one pass, bit-equal to conv(x) + b (+ res) -> relu as
+    separate bfloat16 operations — both memory layouts, with and without residual / ReLU, on the same convolution output."""
+    from rope_s3d_amd import maskrcnn as M
+    torch.manual_seed(3)
+    for cl in (False, True):
+        conv = torch.nn.Conv2d(64, 128, 3, 1, 1).cuda().to(torch.bfloat16)
+        x = torch.randn(2, 64, 24, 40, device='cuda').to(torch.bfloat16)
+        if cl:
+            conv, x = conv.to(memory_format=torch.channels_last), x.contiguous(memory_format=torch.channels_last)
+        raw = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+        res = torch.randn_like(raw)
+        real_conv2d = torch.nn.functional.conv2d
+        monkeypatch.setattr(M.F, 'conv2d', lambda *a, **k: raw.clone())          # the same convolution output for both sides
+        try:
+            for r, relu in ((None, True), (res, True), (res, False), (None, False)):
+                want = raw + conv.bias.view(1, -1, 1, 1)
+                if r is not None:
+                    want = want + r
+                if relu:
+                    want = torch.relu(want)
+                got = M._conv_act(conv, x, res=r, relu=relu)
+                assert got.stride() == want.stride() and torch.equal(got.view(torch.int16), want.view(torch.int16)), (cl, r is not None, relu)
+        finally:
+            monkeypatch.setattr(M.F, 'conv2d', real_conv2d)
