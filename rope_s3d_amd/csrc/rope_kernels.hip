@@ -1395,8 +1395,12 @@ table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned lon
     const float inv_w = 1.0f / (float)max(w, 1);
     auto one = [&](int i, float d) {
         if (i >= m) return;
-        // i / w for i < 2^14, w < 2^11: (i + 0.5) / w is at least 0.5 / w away from an integer, the product's error far less
-        const int r = (int)(((float)i + 0.5f) * inv_w), c = i - r * w;
+        // i / w without an integer division: (i + 0.5) / w is at least 0.5 / w away from an integer and the float product is off
+        // by less than that for i < 2^22; the two corrections make it exact for any crop
+        int r = (int)(((float)i + 0.5f) * inv_w);
+        r -= (r * w > i);
+        r += ((r + 1) * w <= i);
+        const int c = i - r * w;
         const float t = t32c[(r0 + r) * cw + c0 + c];
         acc_sq<false>(s, q32_of_f32(fabsf(t - d)));
         acc_sq<true>(s, q32_of_f32(fabsf(t - 0.0f)));

@@ -256,6 +256,33 @@ def test_lookup_grid_beyond_one_launch():
     assert rc == 0 and np.array_equal(err.view(np.uint64), want.view(np.uint64)) and (bi1.value, be1.value) == (bi0, be0)
 
 
+def test_stored_lookup_table_on_a_large_crop():
+    """The stored table keeps of every row the rectangle that holds its samples and adds the sums of |T| outside it from a
+    per-frame total: at 1280x720 with the whole frame as the crop (rectangles up to ~10^5 samples, rows that hold nothing because
+    the pose leaves the frame, a second target against the same table) the scores equal the loss rendered on the fly, bit for bit."""
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '1280_720_color', ds=1)
+    lim = rb.joint_limits
+    rng = np.random.default_rng(17)
+    grid = rng.uniform(lim[:, 0], lim[:, 1], (300, 6)) * np.array([1, 1, 1, 0, 0, 0])
+    crop = [0, intr.height - 1, 0, intr.width - 1]
+    e.lookup_build(grid, 6, crop)
+    for q in ([0.3, 0.4, 0.9, 0, 0, 0], [-1.2, 0.9, -0.4, 0, 0, 0]):
+        d, ids = e.render(q, 6)
+        tq, t32, flags = helpers.synthetic_target(d, ids)[:3]
+        e.set_target(tq, t32, flags)
+        scores, bi, be = e.lookup_score(want_scores=True)
+        want, _, bi0, be0 = e.eval(grid, 6, eng.LOSS_LOOKUP, crop)
+        assert np.array_equal(scores.view(np.uint64), want.view(np.uint64)) and (bi, be) == (bi0, be0)
+    # a camera that sees nothing of the robot: every row's rectangle is empty, every score the frame's own total
+    e.set_camera(PV @ np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 500.0], [0, 0, 0, 1.0]]), intr.width, intr.height, 0.05, 100.0)
+    e.set_target(tq, t32, flags)
+    e.lookup_build(grid[:40], 6, crop)
+    scores, _, _ = e.lookup_score(want_scores=True)
+    want, _, _, _ = e.eval(grid[:40], 6, eng.LOSS_LOOKUP, crop)
+    assert np.array_equal(scores.view(np.uint64), want.view(np.uint64)) and len(set(scores.tolist())) == 1
+
+
 @pytest.mark.parametrize('seed', list(range(1, 1 + int(__import__('os').environ.get('ROPE_FUZZ_SEEDS', '12')))))
 def test_random_scenes_against_oracle(seed):
     """Random cameras (near, oblique, partly off-screen), all six joints anywhere in their limits, any number of rendered
