@@ -1,9 +1,11 @@
-"""Does a CU-masked stream for the segmentation stage leave room for the engine?  predictor (colour masks) alone, beside the
-network on the default stream, and beside the network on a stream restricted to a fraction of the CUs."""
+#!/usr/bin/env python3
+"""One Predictor alone and beside the network running flat out on a second thread, for several interpreter switch intervals
+(profiles/r02_seg_boxes.txt section 4 also lists the variants with the network on a CU-masked stream and beside threads that
+only hold the interpreter lock or only launch tiny kernels: edit the loop at the end)."""
 import ctypes, os, sys, threading, time
 import numpy as np, torch
 torch.cuda.init()
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd.maskrcnn import MaskRCNNSegmenter
 
 def hip_lib():

@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""Per-frame latency of one Predictor (median, p90, p99, max, frames over 10 ms): shows scheduler freezes if there are any.
+"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd import SyntheticPredictor
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
 sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '1280_720_color', 8, 'SLU', noise=False, seed=1)

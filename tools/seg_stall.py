@@ -1,6 +1,11 @@
+#!/usr/bin/env python3
+"""Per-batch wall time of the segmentation stage with the allocator's and the garbage collector's counters beside it:
+how the every-other-batch 80 ms stall was told apart from allocation, collection, graph replay and pinned memory (NO_PIN=1,
+ROPE_SEG_GRAPH=0, OMP_NUM_THREADS=4 are the switches that were tried; profiles/r02_seg_boxes.txt section 2).
+"""
 import os, sys, time, gc
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd.maskrcnn import MaskRCNNSegmenter
 if os.environ.get('NO_PIN'):
     _empty = torch.empty

@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""Segmentation stage of a batch of eight in parts: upload, moulding, trunk replay, everything after the trunk, results.
+"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd.maskrcnn import MaskRCNNSegmenter
 seg = MaskRCNNSegmenter(7, device='cuda:0', seed=0, min_confidence=0.0)
 net = seg.net
