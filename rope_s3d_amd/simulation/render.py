@@ -28,6 +28,45 @@ def active_robot() -> RobotModel:
     return _robot_cache[key]
 
 
+def shade_depth(depth: np.ndarray, ids: np.ndarray, intr: Intrinsics, ambient: float = 0.12) -> np.ndarray:
+    """Mode 'real' (render.py:92-98 without the SEG flag: the untextured meshes lit by one directional light that sits at the
+    camera and shines along its view axis, render.py:57-59).  The reference's picture comes out of pyrender's physically based
+    shader; this is the same scene with the simplest model of it — grey Lambert surface, head-on light, normals from the
+    rendered depth (differences taken inside one link only, so silhouettes stay sharp) — for the viewers that show it to a
+    person.  Nothing on the prediction path reads this image.  -> (H, W, 3) uint8."""
+    H, W = depth.shape
+    z = depth.astype(np.float64)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    X, Y = (u - intr.cx) / intr.fx * z, (v - intr.cy) / intr.fy * z
+    P = np.stack([X, Y, z], -1)
+
+    def diff(axis):
+        fwd = np.roll(P, -1, axis) - P
+        bwd = P - np.roll(P, 1, axis)
+        ok_f = (np.roll(ids, -1, axis) == ids)
+        ok_b = (np.roll(ids, 1, axis) == ids)
+        edge = np.zeros(ids.shape, bool)
+        if axis == 0:
+            edge[-1, :] = True
+            ok_f &= ~edge
+            edge[:] = False
+            edge[0, :] = True
+            ok_b &= ~edge
+        else:
+            edge[:, -1] = True
+            ok_f &= ~edge
+            edge[:] = False
+            edge[:, 0] = True
+            ok_b &= ~edge
+        return np.where(ok_f[..., None], fwd, np.where(ok_b[..., None], bwd, 0.0))
+    n = np.cross(diff(1), diff(0))
+    norm = np.linalg.norm(n, axis=-1)
+    facing = np.where(norm > 0, np.abs(n[..., 2]) / np.where(norm > 0, norm, 1.0), 1.0)      # light along the view axis: |n . z|
+    shade = np.clip(ambient + (1.0 - ambient) * facing, 0.0, 1.0)
+    grey = np.where(ids != BACKGROUND_ID, np.round(200.0 * shade), 0.0).astype(np.uint8)
+    return np.repeat(grey[..., None], 3, -1)
+
+
 class Renderer:
 
     def __init__(self, mode: str = 'seg', camera_pose: np.ndarray = None,
@@ -59,8 +98,6 @@ class Renderer:
     def setMode(self, mode: str):
         valid_modes = ['seg', 'seg_full', 'real']
         assert mode in valid_modes, f"Mode invalid; must be one of: {valid_modes}"
-        if mode == 'real':
-            raise NotImplementedError("'real' (lit, textured) rendering is not part of the prediction path")
         self.mode = mode
         self._updateMode()
 
@@ -77,7 +114,7 @@ class Renderer:
         self._n_render = n
         if self.mode == 'seg':
             self._colors = [DEFAULT_RENDER_COLORS[i] for i in range(n)]
-        else:
+        else:                                       # 'seg_full'; 'real' shades the surface instead of looking colours up
             self._colors = [DEFAULT_RENDER_COLORS[0]] * n
         lut = np.zeros((256, 3), np.uint8)
         for i, c in enumerate(self._colors):
@@ -97,6 +134,8 @@ class Renderer:
     def render(self):
         """-> (colour uint8 HxWx3, depth float32 HxW), as pyrender's SEG pass (render.py:92-98)."""
         depth, ids = self.render_ids()
+        if self.mode == 'real':
+            return shade_depth(depth, ids, self.intrinsics), depth
         return self._lut[ids], depth
 
     @property

@@ -538,3 +538,25 @@ def test_cpu_budget_and_thread_cap(monkeypatch):
         assert limit_host_threads() == 3
     finally:
         torch.set_num_threads(before)
+
+
+def test_real_mode_shades_a_depth_image():
+    """Renderer mode 'real' (host side): a plane facing the camera is uniformly bright, a tilted one darker, the background
+    black, and the jump between two links does not leak into the normals."""
+    from rope_s3d_amd.projection import Intrinsics
+    from rope_s3d_amd.simulation.render import shade_depth
+    intr = Intrinsics('640_480_color')
+    intr.downscale(8)
+    H, W = intr.height, intr.width
+    depth = np.zeros((H, W), np.float32)
+    ids = np.full((H, W), 255, np.uint8)
+    depth[10:30, 10:30], ids[10:30, 10:30] = 1.5, 0                      # fronto-parallel patch
+    u = np.arange(W, dtype=np.float32)[None, :]
+    depth[35:55, 10:40] = (1.0 + 0.02 * (u - 10))[:, 10:40]              # receding patch, another link right below
+    ids[35:55, 10:40] = 1
+    img = shade_depth(depth, ids, intr)
+    assert img.shape == (H, W, 3) and img.dtype == np.uint8 and (img[..., 0] == img[..., 1]).all()
+    assert (img[ids == 255] == 0).all() and (img[12:28, 12:28, 0] == 200).all()
+    assert (img[10:30, 10:30, 0] == 200).all()                            # its border: differences stay inside the link
+    tilted = img[37:53, 12:38, 0]
+    assert 20 < tilted.mean() < 190 and tilted.std() < 30 and (tilted[0] == tilted[-1]).all()       # darker, and the same along a row of equal depth
