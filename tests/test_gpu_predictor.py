@@ -503,3 +503,25 @@ def test_reference_table_aliasing_over_a_sequence(synth, native):
     # a new camera pose reloads the table (changeCameraPose -> _loadLookup, predict.py:105-117)
     p.changeCameraPose(np.array(DEFAULT_CAMERA_POSE) + [0.01, 0, 0, 0, 0, 0])
     assert np.array_equal(p._lookup_live, p.lookup_angles)
+
+
+def test_renderer_modes_share_one_depth_image():
+    """Renderer 'seg' / 'seg_full' / 'real' (render.py:100-105): the same depth; flat link colours, one colour, or the head-lit
+    shading of mode 'real' (grey, zero on the background, brightest where the surface faces the camera)."""
+    from rope_s3d_amd import Renderer
+    from rope_s3d_amd.constants import DEFAULT_RENDER_COLORS
+    r = Renderer('seg', DEFAULT_CAMERA_POSE, '640_480_color')
+    r.setJointAngles([0.3, 0.4, 0.9, 0, 0, 0])
+    col_seg, d_seg = r.render()
+    r.setMode('seg_full')
+    col_full, d_full = r.render()
+    r.setMode('real')
+    col_real, d_real = r.render()
+    assert np.array_equal(d_seg, d_full) and np.array_equal(d_seg, d_real)
+    on = d_seg > 0
+    assert (col_full[on] == np.array(DEFAULT_RENDER_COLORS[0], np.uint8)).all() and len(np.unique(col_seg[on], axis=0)) > 3
+    assert col_real.shape == col_seg.shape and col_real.dtype == np.uint8
+    assert (col_real[~on] == 0).all() and (col_real[on, 0] > 0).all() and col_real.max() <= 200
+    assert (col_real[..., 0] == col_real[..., 2]).all() and len(np.unique(col_real[on, 0])) > 20
+    with pytest.raises(AssertionError):
+        r.setMode('wireframe')
