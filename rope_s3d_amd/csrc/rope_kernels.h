@@ -41,6 +41,14 @@ constexpr int MAX_MESHLETS = 2048;        // capacity of the per-tile meshlet li
 constexpr int MESHLET_MAX_VERTS = ROPE_MESHLET_MAX_VERTS;
 constexpr int MESHLET_MAX_TRIS = 128;
 constexpr int COMPACT_PX = 60;            // meshlets no larger than this on screen take the 32-bit triangle set-up
+// raster queue: pairs in classes by weight (heaviest first); weights are kept for frames of at most this many tiles
+#ifndef ROPE_QUEUE_CLASSES
+#define ROPE_QUEUE_CLASSES 6
+#endif
+#ifndef ROPE_QUEUE_TOP_LOG2
+#define ROPE_QUEUE_TOP_LOG2 14              // pairs of 2^14 triangles and more are the heaviest class
+#endif
+constexpr int QUEUE_CLASSES = ROPE_QUEUE_CLASSES, QUEUE_TOP_LOG2 = ROPE_QUEUE_TOP_LOG2, QUEUE_COUNTERS = 2 + QUEUE_CLASSES, QUEUE_WEIGHT_TILES = 256;
 constexpr int MAX_MASK_WORDS = 256;        // tile-mask words per candidate (8192 tiles)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t D24_MAX = 16777215u;
@@ -116,12 +124,15 @@ struct RasterArgs {
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
                      const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
-                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters /* 2 ints cleared for launch_raster_queue, or nullptr */);
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
+                     int *queue_counters /* QUEUE_COUNTERS ints cleared for launch_raster_queue, or nullptr */,
+                     uint32_t *tile_tris /* C x n_tiles weights cleared for launch_bounds, or nullptr */, int n_tiles);
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
                          const int32_t *layer_of /* with layer_rep: shared links only for representatives; or nullptr */,
-                         const int32_t *layer_rep);
+                         const int32_t *layer_rep,
+                         uint32_t *tile_tris /* C x n_tiles: triangles of the candidate's own links per tile (n_tiles <= QUEUE_WEIGHT_TILES), or nullptr */);
 // small batches: launch_fk + launch_bounds as one kernel, one workgroup per candidate
 hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const FrameParams &fp, const RobotParams &rp, int n_render,
                             int n_shared, const double *joint_fixed, const double *joint_axes, const double *PV,
@@ -134,7 +145,8 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
 // MODE_SCORE over the (candidate, tile) pairs that have something to draw, from a queue (`items`: rows x tiles entries,
 // `counters`: the two ints launch_fk cleared) by `workgroups` resident workgroups; layer-only tiles are settled on the way
 hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                               const RasterArgs &a, uint32_t *items, int *counters, bool clip);
+                               const RasterArgs &a, uint32_t *items /* QUEUE_CLASSES x segment */, size_t segment, int *counters,
+                               const uint32_t *tile_tris /* weights from launch_bounds, or nullptr: one class */, bool clip);
 // scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)
 hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a);
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,

@@ -112,11 +112,14 @@ __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
               const double *__restrict__ joint_axes, const double *__restrict__ PV_all, const int32_t *__restrict__ view_of,
               float *__restrict__ mvp, uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi,
-              int mask_words, int *__restrict__ queue_counters)
+              int mask_words, int *__restrict__ queue_counters, uint32_t *__restrict__ tile_tris, int n_tiles)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (c == 0 && queue_counters) queue_counters[0] = queue_counters[1] = 0;      // raster_queue_kernel's, filled later in the pass
+    if (c == 0 && queue_counters)                                                 // raster_queue_kernel's, filled later in the pass
+        for (int k = 0; k < QUEUE_COUNTERS; k++) queue_counters[k] = 0;
+    if (tile_tris)
+        for (int k = 0; k < n_tiles; k++) tile_tris[(size_t)c * n_tiles + k] = 0;
     // camera-pose path: every candidate names its own view matrix (camera_pose_prediction.py:116-124)
     const double *__restrict__ PV = PV_all + (view_of ? 16 * (size_t)view_of[c] : 0);
     // first kernel of a pass: clear what the later kernels accumulate into (saves three memset launches)
@@ -464,8 +467,10 @@ __device__ static inline int64_t edge_fn(int32_t ax, int32_t ay, int32_t bx, int
 // Conservative by construction (1 px margin over rounding and sub-pixel snapping): it only ever removes
 // work that cannot produce a sample, never a sample.  Empty boxes are stored as x0 > x1.
 // box of meshlet m under the link matrices `mvp6` (6 x 16 floats); marks the tiles it may touch in s_mask (LDS)
+// s_tris (LDS, one counter per tile, or nullptr): triangles of the candidate's own links (>= n_shared) whose meshlet may touch
+// the tile — the weight of the (candidate, tile) pair in the raster queue
 __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotParams &rp, int m, int n_render, int n_shared,
-                                            const float *mvp6, uint32_t (*s_mask)[MAX_MASK_WORDS])
+                                            const float *mvp6, uint32_t (*s_mask)[MAX_MASK_WORDS], uint32_t *s_tris = nullptr)
 {
     short4 bb = make_short4(1, 0, 1, 0);
     const int l = (int)rp.ml_header[8 * m + 7];
@@ -515,6 +520,7 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
         for (int tx = tx0; tx <= tx1; tx++) {
             const int t = ty * fp.tiles_x + tx;
             atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
+            if (s_tris && l >= n_shared) atomicAdd(&s_tris[t], rp.ml_header[8 * m + 6] >> 16);
         }
     return bb;
 }
@@ -522,11 +528,15 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
 __global__ void __launch_bounds__(256)
 bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const float *__restrict__ mvp_all,
               short4 *__restrict__ bounds, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words,
-              const int32_t *__restrict__ layer_of, const int32_t *__restrict__ layer_rep)
+              const int32_t *__restrict__ layer_of, const int32_t *__restrict__ layer_rep,
+              uint32_t *__restrict__ tile_tris /* C x n_tiles (n_tiles <= QUEUE_WEIGHT_TILES), cleared by fk_mvp_kernel; or nullptr */)
 {
     __shared__ uint32_t s_mask[2][MAX_MASK_WORDS];      // [0]: links < n_shared, [1]: the others
-    const int cand = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_tris[QUEUE_WEIGHT_TILES];
+    const int cand = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x, n_tiles = fp.tiles_x * fp.tiles_y;
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) s_mask[0][i] = s_mask[1][i] = 0;
+    if (tile_tris)
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s_tris[i] = 0;
     __syncthreads();
     // the shared links are only ever drawn for a layer's representative candidate: the others need neither their
     // boxes nor their tile mask (raster_score_kernel reads the representative's mask_lo)
@@ -534,13 +544,17 @@ bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const 
     if (m < rp.n_meshlets) {
         const bool skip = shared_elsewhere && (int)rp.ml_header[8 * m + 7] < n_shared;
         bounds[(size_t)cand * rp.n_meshlets + m] =
-            skip ? make_short4(1, 0, 1, 0) : meshlet_box(fp, rp, m, n_render, n_shared, mvp_all + (size_t)cand * ROPE_MAX_LINKS * 16, s_mask);
+            skip ? make_short4(1, 0, 1, 0) : meshlet_box(fp, rp, m, n_render, n_shared, mvp_all + (size_t)cand * ROPE_MAX_LINKS * 16, s_mask,
+                                                         tile_tris ? s_tris : nullptr);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) {
         if (s_mask[0][i]) atomicOr(&mask_lo[(size_t)cand * mask_words + i], s_mask[0][i]);
         if (s_mask[1][i]) atomicOr(&mask_hi[(size_t)cand * mask_words + i], s_mask[1][i]);
     }
+    if (tile_tris)
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x)
+            if (s_tris[i]) atomicAdd(&tile_tris[(size_t)cand * n_tiles + i], s_tris[i]);
 }
 
 // Small batches: forward kinematics and screen boxes of one candidate in ONE workgroup and one launch.  The five
@@ -1216,19 +1230,27 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 // builds the queue.  A workgroup asks for its next pair while it works on the current one.
 template <int LOSS, bool CLIP>
 __global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
-raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, int *__restrict__ counters /* [0] pairs queued, [1] next */)
+raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, size_t segment,
+                    int *__restrict__ counters /* [1] next ticket, [2 + k] pairs queued in class k */)
 {
     __shared__ int s_item;
     if (threadIdx.x == 0) s_item = atomicAdd(&counters[1], 1);
     __syncthreads();
-    const int n_items = counters[0];
+    // the queue is QUEUE_CLASSES segments of `segment` entries, heaviest pairs first (score_queue_kernel): ticket -> (class, place)
+    int cls_n[QUEUE_CLASSES], n_items = 0;
+#pragma unroll
+    for (int k = 0; k < QUEUE_CLASSES; k++) { cls_n[k] = counters[2 + k]; n_items += cls_n[k]; }
     for (;;) {
         const int item = s_item;
         if (item >= n_items) break;                        // every wave of the workgroup reads the same value: all leave together
         __syncthreads();
         int next = 0;
         if (threadIdx.x == 0) next = atomicAdd(&counters[1], 1);      // in flight while this pair is drawn
-        const uint32_t it = items[item];
+        int place = item, cls = 0;
+#pragma unroll
+        for (int k = 0; k < QUEUE_CLASSES - 1; k++)
+            if (cls == k && place >= cls_n[k]) { place -= cls_n[k]; cls = k + 1; }
+        const uint32_t it = items[(size_t)cls * segment + place];
         raster_tile<LOSS, MODE_SCORE, CLIP>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);
         __syncthreads();                                   // the tile's LDS is free again
         if (threadIdx.x == 0) s_item = next;
@@ -1242,25 +1264,33 @@ raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_
 // 4096 candidates of the bench with one atomic each); where only the shared layer reaches, the candidate takes the
 // layer's stored loss sums here and now.
 __global__ void __launch_bounds__(256)
-score_queue_kernel(RasterArgs ra, int n_rows, int n_tiles, uint32_t *__restrict__ items, int *__restrict__ counters)
+score_queue_kernel(RasterArgs ra, int n_rows, int n_tiles, uint32_t *__restrict__ items, size_t segment, int *__restrict__ counters,
+                   const uint32_t *__restrict__ tile_tris)
 {
-    __shared__ int s_n[8], s_base;
+    __shared__ int s_n[QUEUE_CLASSES], s_base[QUEUE_CLASSES];
     const int k = threadIdx.x & 31, slot = threadIdx.x >> 5, cand = 8 * blockIdx.x + slot, w = blockIdx.y;
     const bool live = cand < n_rows, layers = ra.layer_of != nullptr;
     const uint32_t hi = live ? ra.mask_hi[(size_t)cand * ra.mask_words + w] : 0u;
     const uint32_t lo = live ? ra.mask_lo[(size_t)(layers ? ra.layer_rep[ra.layer_of[cand]] : cand) * ra.mask_words + w] : 0u;
     const uint32_t work = layers ? hi : (hi | lo);
-    if (k == 0) s_n[slot] = __popc(work);
+    if (threadIdx.x < QUEUE_CLASSES) s_n[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-        for (int i = 0; i < 8; i++) total += s_n[i];
-        s_base = total ? atomicAdd(&counters[0], total) : 0;
+    // The heaviest pairs go first: a pair drawing 20 000 triangles takes ten times the average, and one that starts when the
+    // queue is nearly empty keeps its workgroup busy long after the others have left (7 % of the launch was that tail).
+    // Weight = triangles of the meshlets whose boxes touch the tile (bounds_kernel), in classes of a factor two.
+    const bool mine = (work >> k) & 1u;
+    int cls = QUEUE_CLASSES - 1, pos = 0;
+    if (mine) {
+        if (tile_tris) {
+            const uint32_t tris = tile_tris[(size_t)cand * n_tiles + 32 * w + k];
+            cls = min(max(QUEUE_TOP_LOG2 - (31 - __clz((int)(tris | 1u))), 0), QUEUE_CLASSES - 1);     // >= 2^TOP: class 0, a factor two per class
+        }
+        pos = atomicAdd(&s_n[cls], 1);
     }
     __syncthreads();
-    int base = s_base;
-    for (int i = 0; i < slot; i++) base += s_n[i];
-    if ((work >> k) & 1u) items[base + __popc(work & ((1u << k) - 1u))] = (uint32_t)cand | ((uint32_t)(32 * w + k) << 16);
+    if (threadIdx.x < QUEUE_CLASSES) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&counters[2 + threadIdx.x], s_n[threadIdx.x]) : 0;
+    __syncthreads();
+    if (mine) items[(size_t)cls * segment + s_base[cls] + pos] = (uint32_t)cand | ((uint32_t)(32 * w + k) << 16);
     if (layers && live && k < ROPE_SUM_WORDS) {
         uint64_t acc = 0;
         for (uint32_t only = lo & ~hi; only; only &= only - 1) {
@@ -1536,28 +1566,28 @@ static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const R
 }
 
 template <int LOSS>
-static void launch_queue_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a, uint32_t *items, int *counters, bool clip)
+static void launch_queue_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a, uint32_t *items, size_t segment, int *counters, bool clip)
 {
-    if (clip) hipLaunchKernelGGL((raster_queue_kernel<LOSS, true>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, counters);
-    else hipLaunchKernelGGL((raster_queue_kernel<LOSS, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, counters);
+    if (clip) hipLaunchKernelGGL((raster_queue_kernel<LOSS, true>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, segment, counters);
+    else hipLaunchKernelGGL((raster_queue_kernel<LOSS, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, segment, counters);
 }
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
                      const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
-                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters)
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters, uint32_t *tile_tris, int n_tiles)
 {
     hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, view_of,
-                       mvp, sums, mask_lo, mask_hi, mask_words, queue_counters);
+                       mvp, sums, mask_lo, mask_hi, mask_words, queue_counters, tile_tris, n_tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
-                         const int32_t *layer_of, const int32_t *layer_rep)
+                         const int32_t *layer_of, const int32_t *layer_rep, uint32_t *tile_tris)
 {
-    // the masks were cleared by fk_mvp_kernel earlier in the same pass
+    // the masks (and the tile weights) were cleared by fk_mvp_kernel earlier in the same pass
     hipLaunchKernelGGL(bounds_kernel, dim3((rp.n_meshlets + 255) / 256, C), dim3(256), 0, st, fp, rp, n_render, n_shared, mvp,
-                       bounds, mask_lo, mask_hi, mask_words, layer_of, layer_rep);
+                       bounds, mask_lo, mask_hi, mask_words, layer_of, layer_rep, tile_tris);
     return hipGetLastError();
 }
 
@@ -1594,17 +1624,17 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
 }
 
 hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
-                               const RasterArgs &a, uint32_t *items, int *counters, bool clip)
+                               const RasterArgs &a, uint32_t *items, size_t segment, int *counters, const uint32_t *tile_tris, bool clip)
 {
     const int n_tiles = fp.tiles_x * fp.tiles_y;
-    hipLaunchKernelGGL(score_queue_kernel, dim3((rows + 7) / 8, a.mask_words), dim3(256), 0, st, a, rows, n_tiles, items, counters);
+    hipLaunchKernelGGL(score_queue_kernel, dim3((rows + 7) / 8, a.mask_words), dim3(256), 0, st, a, rows, n_tiles, items, segment, counters, tile_tris);
     const dim3 grid(workgroups);
     switch (loss) {
-    case ROPE_LOSS_DEPTH: launch_queue_one<ROPE_LOSS_DEPTH>(grid, st, fp, rp, a, items, counters, clip); break;
-    case ROPE_LOSS_FULL: launch_queue_one<ROPE_LOSS_FULL>(grid, st, fp, rp, a, items, counters, clip); break;
-    case ROPE_LOSS_LOOKUP: launch_queue_one<ROPE_LOSS_LOOKUP>(grid, st, fp, rp, a, items, counters, clip); break;
-    case ROPE_LOSS_CAMFULL: launch_queue_one<ROPE_LOSS_CAMFULL>(grid, st, fp, rp, a, items, counters, clip); break;
-    default: launch_queue_one<ROPE_LOSS_TSWEEP>(grid, st, fp, rp, a, items, counters, clip); break;
+    case ROPE_LOSS_DEPTH: launch_queue_one<ROPE_LOSS_DEPTH>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_FULL: launch_queue_one<ROPE_LOSS_FULL>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_LOOKUP: launch_queue_one<ROPE_LOSS_LOOKUP>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_CAMFULL: launch_queue_one<ROPE_LOSS_CAMFULL>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    default: launch_queue_one<ROPE_LOSS_TSWEEP>(grid, st, fp, rp, a, items, segment, counters, clip); break;
     }
     return hipGetLastError();
 }
