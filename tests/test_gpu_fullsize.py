@@ -256,6 +256,39 @@ def test_lookup_grid_beyond_one_launch():
     assert rc == 0 and np.array_equal(err.view(np.uint64), want.view(np.uint64)) and (bi1.value, be1.value) == (bi0, be0)
 
 
+def test_frames_of_more_than_256_tiles():
+    """2560x1440 is 20 x 15 = 300 tiles: more than the raster queue keeps per-tile weights for, so its pairs go in candidate
+    order in one segment.  600 candidates through the queue equal the one-workgroup-per-pair launch, the unshared form, and the
+    oracle on a sample."""
+    rb = helpers.robot()
+    from rope_s3d_amd.projection import Intrinsics, view_matrix
+    intr = Intrinsics('[ 2560x1440  p[1276.78 722.986]  f[1810.46 1809.72]  Inverse Brown Conrady [0 0 0 0 0] ]')
+    assert -(-intr.width // 128) * -(-intr.height // 96) > 256
+    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+    o = helpers.make_oracle(rb, intr, PV)
+    d, ids = e.render([0.3, 0.4, 0.9, 0, 0, 0], 6)
+    tq, t32, flags = helpers.synthetic_target(d, ids)[:3]
+    e.set_target(tq, t32, flags)
+    rng = np.random.default_rng(23)
+    lim = rb.joint_limits
+    cand = np.array([0.3, 0.4, 0.9, 0, 0, 0]) + rng.uniform(-0.4, 0.4, (600, 6)) * np.array([1, 1, 1, 0, 0, 0])
+    cand[::3, :2] = cand[0, :2]                                        # some rows share their first two joints: layers
+    err_a, sums_a, bi_a, _ = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+    for flag in (e.NO_QUEUE, e.NO_LAYERS):
+        e.set_strategy(flag)
+        try:
+            err_b, sums_b, bi_b, _ = e.eval(cand, 6, eng.LOSS_DEPTH, want_sums=True)
+        finally:
+            e.set_strategy(0)
+        assert np.array_equal(sums_a, sums_b) and bi_a == bi_b, flag
+    pick = rng.choice(len(cand), 6, replace=False)
+    ref = o.eval(cand[pick], orc.LOSS_DEPTH, 6, tq, t32, None, flags, threads=6)
+    assert np.array_equal(err_a[pick].view(np.uint64), ref.view(np.uint64))
+
+
 def test_stored_lookup_table_on_a_large_crop():
     """The stored table keeps of every row the rectangle that holds its samples and adds the sums of |T| outside it from a
     per-frame total: at 1280x720 with the whole frame as the crop (rectangles up to ~10^5 samples, rows that hold nothing because
