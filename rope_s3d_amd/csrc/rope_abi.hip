@@ -95,7 +95,7 @@ struct rope_ctx {
     int layer_min_wg = 64;                 // fewest busy workgroups of a shared-layer launch for it to pay in a small batch (layers_pay)
     int strategy = 0;                          // STRATEGY_* bits (rope_set_strategy): launch structure only, never a result
     // large batches: queue of the (candidate, tile) pairs with something to draw, worked off by a grid that just fills the chip
-    uint32_t *d_qitems = nullptr, *d_tile_tris = nullptr;
+    uint32_t *d_qitems = nullptr, *d_tile_tris = nullptr, *d_tile_tris_lo = nullptr;
     size_t q_segment = 0;
     bool q_weighted = false;
     int *d_qctr = nullptr;                     // [0] pairs queued, [1] next pair to hand out; cleared by fk_mvp_kernel
@@ -199,7 +199,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
         hipHostMalloc((void **)&c->h_cand, 6 * rope_ctx::HOST_ERR_ROWS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_cand_host, c->h_cand, 0) != hipSuccess ||
         hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void **)&c->d_qctr, QUEUE_COUNTERS * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_qctr, 2 * QUEUE_COUNTERS * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_best_err, sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_PV, 16 * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&c->d_joint_fixed, 72 * sizeof(double)) != hipSuccess ||
@@ -246,7 +246,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_qctr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -507,11 +507,15 @@ static int ensure_capacity(rope_ctx *c, int C)
     // raster queue: QUEUE_CLASSES segments (pairs by weight, heaviest first) and the per-(candidate, tile) weights, when the frame
     // has few enough tiles for the weights and the segments stay small; otherwise one segment, pairs in candidate order
     const size_t seg = (size_t)cap * c->mask_words * 32;
-    c->q_weighted = c->n_tiles <= QUEUE_WEIGHT_TILES && seg * QUEUE_CLASSES * sizeof(uint32_t) <= ((size_t)512 << 20);
+    c->q_weighted = c->n_tiles <= QUEUE_WEIGHT_TILES && 2 * seg * QUEUE_CLASSES * sizeof(uint32_t) <= ((size_t)512 << 20);
     c->q_segment = c->q_weighted ? seg : 0;
-    HIP_TRY(c, realloc_dev(&c->d_qitems, c->q_weighted ? seg * QUEUE_CLASSES : seg));
+    HIP_TRY(c, realloc_dev(&c->d_qitems, c->q_weighted ? 2 * seg * QUEUE_CLASSES : seg));      // weighted: the scoring queue, then the layer queue
     if (c->d_tile_tris) { (void)hipFree(c->d_tile_tris); c->d_tile_tris = nullptr; }
-    if (c->q_weighted) HIP_TRY(c, realloc_dev(&c->d_tile_tris, (size_t)cap * c->n_tiles));
+    if (c->d_tile_tris_lo) { (void)hipFree(c->d_tile_tris_lo); c->d_tile_tris_lo = nullptr; }
+    if (c->q_weighted) {
+        HIP_TRY(c, realloc_dev(&c->d_tile_tris, (size_t)cap * c->n_tiles));
+        HIP_TRY(c, realloc_dev(&c->d_tile_tris_lo, (size_t)cap * c->n_tiles));
+    }
     c->cap = cap;
     return ROPE_OK;
 }
@@ -645,6 +649,7 @@ static int ensure_layers(rope_ctx *c)
 }
 
 static bool want_parents(const rope_ctx *c) { return c->n_parents * 4 <= c->n_layers; }
+static uint32_t *queue_weights(const rope_ctx *c);
 
 // The shared links of every layer into c->d_layers (+ their loss sums when `la` carries targets and layer_sums).
 // Two levels when many layers share their first joint angle: links 0-1 once per distinct q0, then link 2 per layer
@@ -666,6 +671,13 @@ static int enqueue_layers(rope_ctx *c, RasterArgs la, int loss, int n_shared, co
     } else {
         la.l_begin = 0; la.l_end = n_shared;
     }
+    if (queue_weights(c) && !(c->strategy & STRATEGY_NO_QUEUE)) {
+        // the (layer, tile) pairs that have anything to draw, heaviest first, to a grid that just fills the chip: of the one-
+        // workgroup-per-pair launch's 266 us the last 100 ran with a third of the chip (a 140 us pair that started at 150 us)
+        HIP_TRY(c, launch_layer_queue(loss, c->n_layers, 2 * c->n_cu, c->stream, fp, c->rp, la, c->d_qitems + QUEUE_CLASSES * c->q_segment,
+                                      c->q_segment, c->d_qctr + QUEUE_COUNTERS, c->d_tile_tris_lo, use_clip(c)));
+        return ROPE_OK;
+    }
     HIP_TRY(c, launch_raster(MODE_LAYER, loss, c->n_layers, c->stream, fp, c->rp, la, use_clip(c)));
     return ROPE_OK;
 }
@@ -686,7 +698,7 @@ static RasterArgs base_args(rope_ctx *c, int n_render)
 static uint32_t *queue_weights(const rope_ctx *c)
 {
     const size_t busy_tiles = (size_t)std::max(std::min(2, c->n_tiles), c->n_tiles / 3);
-    return (c->q_weighted && (size_t)c->C * busy_tiles <= (size_t)256 * 2 * c->n_cu) ? c->d_tile_tris : nullptr;
+    return (c->q_weighted && c->C > 256 && (size_t)c->C * busy_tiles <= (size_t)256 * 2 * c->n_cu) ? c->d_tile_tris : nullptr;     // C <= 256: fk_bounds_kernel, no weights
 }
 
 // forward kinematics + link matrices + screen boxes + tile masks (+ cleared sums) of the resident candidates
@@ -700,9 +712,11 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
         return ROPE_OK;
     }
     HIP_TRY(c, launch_fk(c->stream, cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
-                         c->d_mask_lo, c->d_mask_hi, c->mask_words, c->d_qctr, queue_weights(c), c->n_tiles));
+                         c->d_mask_lo, c->d_mask_hi, c->mask_words, c->d_qctr, queue_weights(c), c->d_tile_tris_lo, c->n_tiles));
+    // weights of the shared links for the layer launch: with the second level in use it draws the last shared link only
+    const int lo_first = (n_shared == 3 && want_parents(c) && !(c->strategy & STRATEGY_NO_PARENTS)) ? 2 : 0;
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words,
-                             n_shared > 0 ? c->d_layer_of : nullptr, n_shared > 0 ? c->d_layer_rep : nullptr, queue_weights(c)));
+                             n_shared > 0 ? c->d_layer_of : nullptr, n_shared > 0 ? c->d_layer_rep : nullptr, queue_weights(c), c->d_tile_tris_lo, lo_first));
     return ROPE_OK;
 }
 

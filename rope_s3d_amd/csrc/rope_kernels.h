@@ -125,14 +125,16 @@ struct RasterArgs {
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
                      const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
                      uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
-                     int *queue_counters /* QUEUE_COUNTERS ints cleared for launch_raster_queue, or nullptr */,
-                     uint32_t *tile_tris /* C x n_tiles weights cleared for launch_bounds, or nullptr */, int n_tiles);
+                     int *queue_counters /* 2 x QUEUE_COUNTERS ints cleared for launch_raster_queue and launch_layer_queue, or nullptr */,
+                     uint32_t *tile_tris /* C x n_tiles weights cleared for launch_bounds, or nullptr */, uint32_t *tile_tris_lo /* with tile_tris */,
+                     int n_tiles);
 // screen bounding box of every meshlet of every candidate + the candidate's masks of touched tiles
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
                          const int32_t *layer_of /* with layer_rep: shared links only for representatives; or nullptr */,
                          const int32_t *layer_rep,
-                         uint32_t *tile_tris /* C x n_tiles: triangles of the candidate's own links per tile (n_tiles <= QUEUE_WEIGHT_TILES), or nullptr */);
+                         uint32_t *tile_tris /* C x n_tiles: triangles of the candidate's own links per tile (n_tiles <= QUEUE_WEIGHT_TILES), or nullptr */,
+                         uint32_t *tile_tris_lo /* with tile_tris: the same for the shared links lo_first .. n_shared - 1 */, int lo_first);
 // small batches: launch_fk + launch_bounds as one kernel, one workgroup per candidate
 hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const FrameParams &fp, const RobotParams &rp, int n_render,
                             int n_shared, const double *joint_fixed, const double *joint_axes, const double *PV,
@@ -147,6 +149,9 @@ hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const Fra
 hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                                const RasterArgs &a, uint32_t *items /* QUEUE_CLASSES x segment */, size_t segment, int *counters,
                                const uint32_t *tile_tris /* weights from launch_bounds, or nullptr: one class */, bool clip);
+// the same for a MODE_LAYER launch (a.cand_of_row set): (layer, tile) pairs of the representatives' shared links, by their weight
+hipError_t launch_layer_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                              const RasterArgs &a, uint32_t *items, size_t segment, int *counters, const uint32_t *tile_tris_lo, bool clip);
 // scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)
 hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a);
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,

@@ -112,14 +112,14 @@ __global__ void __launch_bounds__(256)
 fk_mvp_kernel(const double *__restrict__ cand, int C, int n_render, const double *__restrict__ joint_fixed,
               const double *__restrict__ joint_axes, const double *__restrict__ PV_all, const int32_t *__restrict__ view_of,
               float *__restrict__ mvp, uint64_t *__restrict__ sums, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi,
-              int mask_words, int *__restrict__ queue_counters, uint32_t *__restrict__ tile_tris, int n_tiles)
+              int mask_words, int *__restrict__ queue_counters, uint32_t *__restrict__ tile_tris, uint32_t *__restrict__ tile_tris_lo, int n_tiles)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (c == 0 && queue_counters)                                                 // raster_queue_kernel's, filled later in the pass
-        for (int k = 0; k < QUEUE_COUNTERS; k++) queue_counters[k] = 0;
+        for (int k = 0; k < 2 * QUEUE_COUNTERS; k++) queue_counters[k] = 0;      // the scoring queue's, then the layer queue's
     if (tile_tris)
-        for (int k = 0; k < n_tiles; k++) tile_tris[(size_t)c * n_tiles + k] = 0;
+        for (int k = 0; k < n_tiles; k++) tile_tris[(size_t)c * n_tiles + k] = tile_tris_lo[(size_t)c * n_tiles + k] = 0;
     // camera-pose path: every candidate names its own view matrix (camera_pose_prediction.py:116-124)
     const double *__restrict__ PV = PV_all + (view_of ? 16 * (size_t)view_of[c] : 0);
     // first kernel of a pass: clear what the later kernels accumulate into (saves three memset launches)
@@ -470,7 +470,8 @@ __device__ static inline int64_t edge_fn(int32_t ax, int32_t ay, int32_t bx, int
 // s_tris (LDS, one counter per tile, or nullptr): triangles of the candidate's own links (>= n_shared) whose meshlet may touch
 // the tile — the weight of the (candidate, tile) pair in the raster queue
 __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotParams &rp, int m, int n_render, int n_shared,
-                                            const float *mvp6, uint32_t (*s_mask)[MAX_MASK_WORDS], uint32_t *s_tris = nullptr)
+                                            const float *mvp6, uint32_t (*s_mask)[MAX_MASK_WORDS], uint32_t *s_tris = nullptr,
+                                            uint32_t *s_tris_lo = nullptr /* the same for the shared links lo_first .. n_shared - 1 */, int lo_first = 0)
 {
     short4 bb = make_short4(1, 0, 1, 0);
     const int l = (int)rp.ml_header[8 * m + 7];
@@ -521,6 +522,7 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
             const int t = ty * fp.tiles_x + tx;
             atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
             if (s_tris && l >= n_shared) atomicAdd(&s_tris[t], rp.ml_header[8 * m + 6] >> 16);
+            if (s_tris_lo && l < n_shared && l >= lo_first) atomicAdd(&s_tris_lo[t], rp.ml_header[8 * m + 6] >> 16);
         }
     return bb;
 }
@@ -529,14 +531,15 @@ __global__ void __launch_bounds__(256)
 bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const float *__restrict__ mvp_all,
               short4 *__restrict__ bounds, uint32_t *__restrict__ mask_lo, uint32_t *__restrict__ mask_hi, int mask_words,
               const int32_t *__restrict__ layer_of, const int32_t *__restrict__ layer_rep,
-              uint32_t *__restrict__ tile_tris /* C x n_tiles (n_tiles <= QUEUE_WEIGHT_TILES), cleared by fk_mvp_kernel; or nullptr */)
+              uint32_t *__restrict__ tile_tris /* C x n_tiles (n_tiles <= QUEUE_WEIGHT_TILES), cleared by fk_mvp_kernel; or nullptr */,
+              uint32_t *__restrict__ tile_tris_lo /* with tile_tris: the same for the shared links lo_first .. n_shared - 1 */, int lo_first)
 {
     __shared__ uint32_t s_mask[2][MAX_MASK_WORDS];      // [0]: links < n_shared, [1]: the others
-    __shared__ uint32_t s_tris[QUEUE_WEIGHT_TILES];
+    __shared__ uint32_t s_tris[QUEUE_WEIGHT_TILES], s_tris_lo[QUEUE_WEIGHT_TILES];
     const int cand = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x, n_tiles = fp.tiles_x * fp.tiles_y;
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) s_mask[0][i] = s_mask[1][i] = 0;
     if (tile_tris)
-        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s_tris[i] = 0;
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s_tris[i] = s_tris_lo[i] = 0;
     __syncthreads();
     // the shared links are only ever drawn for a layer's representative candidate: the others need neither their
     // boxes nor their tile mask (raster_score_kernel reads the representative's mask_lo)
@@ -545,7 +548,7 @@ bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const 
         const bool skip = shared_elsewhere && (int)rp.ml_header[8 * m + 7] < n_shared;
         bounds[(size_t)cand * rp.n_meshlets + m] =
             skip ? make_short4(1, 0, 1, 0) : meshlet_box(fp, rp, m, n_render, n_shared, mvp_all + (size_t)cand * ROPE_MAX_LINKS * 16, s_mask,
-                                                         tile_tris ? s_tris : nullptr);
+                                                         tile_tris ? s_tris : nullptr, tile_tris ? s_tris_lo : nullptr, lo_first);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < mask_words; i += blockDim.x) {
@@ -553,8 +556,10 @@ bounds_kernel(FrameParams fp, RobotParams rp, int n_render, int n_shared, const 
         if (s_mask[1][i]) atomicOr(&mask_hi[(size_t)cand * mask_words + i], s_mask[1][i]);
     }
     if (tile_tris)
-        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x)
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
             if (s_tris[i]) atomicAdd(&tile_tris[(size_t)cand * n_tiles + i], s_tris[i]);
+            if (s_tris_lo[i]) atomicAdd(&tile_tris_lo[(size_t)cand * n_tiles + i], s_tris_lo[i]);
+        }
 }
 
 // Small batches: forward kinematics and screen boxes of one candidate in ONE workgroup and one launch.  The five
@@ -1228,7 +1233,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 // chip (two workgroups per CU) — of the tiles x candidates pairs of a pass about four in five have nothing to do, and a
 // launch over all of them spends a fifth of a millisecond starting workgroups that leave at once.  score_queue_kernel
 // builds the queue.  A workgroup asks for its next pair while it works on the current one.
-template <int LOSS, bool CLIP>
+template <int LOSS, int MODE, bool CLIP>
 __global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
 raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, size_t segment,
                     int *__restrict__ counters /* [1] next ticket, [2 + k] pairs queued in class k */)
@@ -1251,7 +1256,7 @@ raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_
         for (int k = 0; k < QUEUE_CLASSES - 1; k++)
             if (cls == k && place >= cls_n[k]) { place -= cls_n[k]; cls = k + 1; }
         const uint32_t it = items[(size_t)cls * segment + place];
-        raster_tile<LOSS, MODE_SCORE, CLIP>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);
+        raster_tile<LOSS, MODE, CLIP>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);      // row = candidate (MODE_SCORE) or layer (MODE_LAYER)
         __syncthreads();                                   // the tile's LDS is free again
         if (threadIdx.x == 0) s_item = next;
         __syncthreads();
@@ -1269,10 +1274,13 @@ score_queue_kernel(RasterArgs ra, int n_rows, int n_tiles, uint32_t *__restrict_
 {
     __shared__ int s_n[QUEUE_CLASSES], s_base[QUEUE_CLASSES];
     const int k = threadIdx.x & 31, slot = threadIdx.x >> 5, cand = 8 * blockIdx.x + slot, w = blockIdx.y;
-    const bool live = cand < n_rows, layers = ra.layer_of != nullptr;
-    const uint32_t hi = live ? ra.mask_hi[(size_t)cand * ra.mask_words + w] : 0u;
-    const uint32_t lo = live ? ra.mask_lo[(size_t)(layers ? ra.layer_rep[ra.layer_of[cand]] : cand) * ra.mask_words + w] : 0u;
-    const uint32_t work = layers ? hi : (hi | lo);
+    // rows of a shared-layer launch (ra.cand_of_row set): the pairs its representative candidate's shared links reach, weighed by
+    // those links' triangles (tile_tris is the shared links' array then)
+    const bool live = cand < n_rows, for_layers = ra.cand_of_row != nullptr, layers = !for_layers && ra.layer_of != nullptr;
+    const int rep = (live && for_layers) ? ra.cand_of_row[cand] : cand;
+    const uint32_t hi = (live && !for_layers) ? ra.mask_hi[(size_t)cand * ra.mask_words + w] : 0u;
+    const uint32_t lo = live ? ra.mask_lo[(size_t)(layers ? ra.layer_rep[ra.layer_of[cand]] : rep) * ra.mask_words + w] : 0u;
+    const uint32_t work = for_layers ? lo : (layers ? hi : (hi | lo));
     if (threadIdx.x < QUEUE_CLASSES) s_n[threadIdx.x] = 0;
     __syncthreads();
     // The heaviest pairs go first: a pair drawing 20 000 triangles takes ten times the average, and one that starts when the
@@ -1282,7 +1290,7 @@ score_queue_kernel(RasterArgs ra, int n_rows, int n_tiles, uint32_t *__restrict_
     int cls = QUEUE_CLASSES - 1, pos = 0;
     if (mine) {
         if (tile_tris) {
-            const uint32_t tris = tile_tris[(size_t)cand * n_tiles + 32 * w + k];
+            const uint32_t tris = tile_tris[(size_t)rep * n_tiles + 32 * w + k];
             cls = min(max(QUEUE_TOP_LOG2 - (31 - __clz((int)(tris | 1u))), 0), QUEUE_CLASSES - 1);     // >= 2^TOP: class 0, a factor two per class
         }
         pos = atomicAdd(&s_n[cls], 1);
@@ -1565,29 +1573,30 @@ static void launch_one(dim3 grid, hipStream_t st, const FrameParams &fp, const R
     else hipLaunchKernelGGL((raster_score_kernel<LOSS, MODE, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a);
 }
 
-template <int LOSS>
+template <int LOSS, int MODE>
 static void launch_queue_one(dim3 grid, hipStream_t st, const FrameParams &fp, const RobotParams &rp, const RasterArgs &a, uint32_t *items, size_t segment, int *counters, bool clip)
 {
-    if (clip) hipLaunchKernelGGL((raster_queue_kernel<LOSS, true>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, segment, counters);
-    else hipLaunchKernelGGL((raster_queue_kernel<LOSS, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, segment, counters);
+    if (clip) hipLaunchKernelGGL((raster_queue_kernel<LOSS, MODE, true>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, segment, counters);
+    else hipLaunchKernelGGL((raster_queue_kernel<LOSS, MODE, false>), grid, dim3(NTHREADS), 0, st, fp, rp, a, items, segment, counters);
 }
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,
                      const double *joint_axes, const double *PV, const int32_t *view_of, float *mvp, uint64_t *sums,
-                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters, uint32_t *tile_tris, int n_tiles)
+                     uint32_t *mask_lo, uint32_t *mask_hi, int mask_words, int *queue_counters, uint32_t *tile_tris, uint32_t *tile_tris_lo,
+                     int n_tiles)
 {
     hipLaunchKernelGGL(fk_mvp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cand, C, n_render, joint_fixed, joint_axes, PV, view_of,
-                       mvp, sums, mask_lo, mask_hi, mask_words, queue_counters, tile_tris, n_tiles);
+                       mvp, sums, mask_lo, mask_hi, mask_words, queue_counters, tile_tris, tile_tris_lo, n_tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_bounds(hipStream_t st, int C, const FrameParams &fp, const RobotParams &rp, int n_render, int n_shared,
                          const float *mvp, short4 *bounds, uint32_t *mask_lo, uint32_t *mask_hi, int mask_words,
-                         const int32_t *layer_of, const int32_t *layer_rep, uint32_t *tile_tris)
+                         const int32_t *layer_of, const int32_t *layer_rep, uint32_t *tile_tris, uint32_t *tile_tris_lo, int lo_first)
 {
     // the masks (and the tile weights) were cleared by fk_mvp_kernel earlier in the same pass
     hipLaunchKernelGGL(bounds_kernel, dim3((rp.n_meshlets + 255) / 256, C), dim3(256), 0, st, fp, rp, n_render, n_shared, mvp,
-                       bounds, mask_lo, mask_hi, mask_words, layer_of, layer_rep, tile_tris);
+                       bounds, mask_lo, mask_hi, mask_words, layer_of, layer_rep, tile_tris, tile_tris_lo, lo_first);
     return hipGetLastError();
 }
 
@@ -1630,12 +1639,25 @@ hipError_t launch_raster_queue(int loss, int rows, int workgroups, hipStream_t s
     hipLaunchKernelGGL(score_queue_kernel, dim3((rows + 7) / 8, a.mask_words), dim3(256), 0, st, a, rows, n_tiles, items, segment, counters, tile_tris);
     const dim3 grid(workgroups);
     switch (loss) {
-    case ROPE_LOSS_DEPTH: launch_queue_one<ROPE_LOSS_DEPTH>(grid, st, fp, rp, a, items, segment, counters, clip); break;
-    case ROPE_LOSS_FULL: launch_queue_one<ROPE_LOSS_FULL>(grid, st, fp, rp, a, items, segment, counters, clip); break;
-    case ROPE_LOSS_LOOKUP: launch_queue_one<ROPE_LOSS_LOOKUP>(grid, st, fp, rp, a, items, segment, counters, clip); break;
-    case ROPE_LOSS_CAMFULL: launch_queue_one<ROPE_LOSS_CAMFULL>(grid, st, fp, rp, a, items, segment, counters, clip); break;
-    default: launch_queue_one<ROPE_LOSS_TSWEEP>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_DEPTH: launch_queue_one<ROPE_LOSS_DEPTH, MODE_SCORE>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_FULL: launch_queue_one<ROPE_LOSS_FULL, MODE_SCORE>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_LOOKUP: launch_queue_one<ROPE_LOSS_LOOKUP, MODE_SCORE>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    case ROPE_LOSS_CAMFULL: launch_queue_one<ROPE_LOSS_CAMFULL, MODE_SCORE>(grid, st, fp, rp, a, items, segment, counters, clip); break;
+    default: launch_queue_one<ROPE_LOSS_TSWEEP, MODE_SCORE>(grid, st, fp, rp, a, items, segment, counters, clip); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_layer_queue(int loss, int rows, int workgroups, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
+                              const RasterArgs &a, uint32_t *items, size_t segment, int *counters, const uint32_t *tile_tris_lo, bool clip)
+{
+    const int n_tiles = fp.tiles_x * fp.tiles_y;
+    hipLaunchKernelGGL(score_queue_kernel, dim3((rows + 7) / 8, a.mask_words), dim3(256), 0, st, a, rows, n_tiles, items, segment, counters, tile_tris_lo);
+    const dim3 grid(workgroups);
+    if (loss == ROPE_LOSS_DEPTH) launch_queue_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a, items, segment, counters, clip);
+    else if (loss == ROPE_LOSS_FULL) launch_queue_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a, items, segment, counters, clip);
+    else if (loss == ROPE_LOSS_LOOKUP) launch_queue_one<ROPE_LOSS_LOOKUP, MODE_LAYER>(grid, st, fp, rp, a, items, segment, counters, clip);
+    else launch_queue_one<ROPE_LOSS_TSWEEP, MODE_LAYER>(grid, st, fp, rp, a, items, segment, counters, clip);
     return hipGetLastError();
 }
 
