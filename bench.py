@@ -319,7 +319,7 @@ def main():
                          "measured_hbm_frac": (traffic / (kern['score'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "binding_resource": "vector instruction issue (valu_issue below), not HBM",
                          "valu_issue": valu,
-                         "kernel": "raster_queue_kernel<%s> (per-candidate links + loss, from the queue of (candidate, tile) pairs) + raster_score_kernel<%s,LAYER> launches (links 0-2 once per distinct (S,L))" % ((args.loss.upper(),) * 2),
+                         "kernel": "raster_queue_kernel<%s,SCORE> (per-candidate links + loss, from the queue of (candidate, tile) pairs, heaviest first) + the shared-layer launches raster_score_kernel / raster_queue_kernel<%s,LAYER> (links 0-2 once per distinct (S,L))" % ((args.loss.upper(),) * 2),
                          "kernel_ms": kern['raster'], "score_launch_ms": kern['score'], "layer_launch_ms": kern['layer'],
                          "bytes_per_candidate": b_cand, "candidates_per_launch": C,
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],

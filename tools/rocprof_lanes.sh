@@ -6,7 +6,7 @@ python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(glob.glob('/tmp/prof_lanes/*/*_counter_collection.csv')[0])):
-    k = 'SCORE' if ('raster_queue_kernel<0' in r['Kernel_Name'] or 'raster_score_kernel<0, 0' in r['Kernel_Name']) else ('LAYER' if 'raster_score_kernel<0, 3>' in r['Kernel_Name'] else None)
+    k = 'SCORE' if ('raster_queue_kernel<0, 0' in r['Kernel_Name'] or 'raster_score_kernel<0, 0' in r['Kernel_Name']) else ('LAYER' if ('raster_score_kernel<0, 3' in r['Kernel_Name'] or 'raster_queue_kernel<0, 3' in r['Kernel_Name']) else None)
     if k: agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}

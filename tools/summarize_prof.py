@@ -34,7 +34,7 @@ pmc = collections.defaultdict(list)
 for d in ('pmc_sq', 'pmc_sq2', 'pmc_lanes', 'pmc_fetch', 'pmc_write'):
     for f in newest(os.path.join(src, d, '*', '*_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
-            if 'raster_queue_kernel<0' in r['Kernel_Name'] or 'raster_score_kernel<0, 0' in r['Kernel_Name']:
+            if 'raster_queue_kernel<0, 0' in r['Kernel_Name'] or 'raster_score_kernel<0, 0' in r['Kernel_Name']:       # <LOSS = DEPTH, MODE = SCORE>
                 pmc[r['Counter_Name']].append(float(r['Counter_Value']))
 summary = {k: {'launches': len(v), 'avg_per_launch': sum(v) / len(v)} for k, v in sorted(pmc.items())}
 if 'SQ_THREAD_CYCLES_VALU' in summary and 'SQ_ACTIVE_INST_VALU' in pmc:
@@ -42,7 +42,7 @@ if 'SQ_THREAD_CYCLES_VALU' in summary and 'SQ_ACTIVE_INST_VALU' in pmc:
     lanes = [t / a for t, a in zip(pmc['SQ_THREAD_CYCLES_VALU'][-len(pmc['SQ_ACTIVE_INST_VALU']):], pmc['SQ_ACTIVE_INST_VALU'][-len(pmc['SQ_THREAD_CYCLES_VALU']):]) if a]
     if lanes:
         summary['active_lanes'] = {'launches': len(lanes), 'avg_per_launch': sum(lanes) / len(lanes)}
-json.dump({'kernel': 'raster_queue_kernel<DEPTH> (the scoring launch of large batches; raster_score_kernel<DEPTH,SCORE> before the queue)', 'command': 'bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-unshared',
+json.dump({'kernel': 'raster_queue_kernel<DEPTH,SCORE> (the scoring launch of large batches; raster_score_kernel<DEPTH,SCORE> before the queue)', 'command': 'bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-unshared',
            'counters': summary}, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
 if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
     fetch_kb, write_kb = summary['FETCH_SIZE']['avg_per_launch'], summary['WRITE_SIZE']['avg_per_launch']
