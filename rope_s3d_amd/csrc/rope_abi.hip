@@ -650,6 +650,14 @@ static int ensure_layers(rope_ctx *c)
 
 static bool want_parents(const rope_ctx *c) { return c->n_parents * 4 <= c->n_layers; }
 static uint32_t *queue_weights(const rope_ctx *c);
+// Second level of sharing (links 0-1 once per distinct q0): pays when the layers are a launch of one workgroup per (layer, tile)
+// pair — not when they go through the weighted queue, which draws links 0-2 per layer faster than the extra launch of a
+// hundred busy workgroups plus the merge of every layer tile with its parent's (0.264 against 0.283 ms on the bench workload).
+static bool use_parents(const rope_ctx *c, int n_shared)
+{
+    if (n_shared != 3 || !want_parents(c) || (c->strategy & STRATEGY_NO_PARENTS)) return false;
+    return !(queue_weights(c) && !(c->strategy & STRATEGY_NO_QUEUE));
+}
 
 // The shared links of every layer into c->d_layers (+ their loss sums when `la` carries targets and layer_sums).
 // Two levels when many layers share their first joint angle: links 0-1 once per distinct q0, then link 2 per layer
@@ -657,7 +665,7 @@ static uint32_t *queue_weights(const rope_ctx *c);
 static int enqueue_layers(rope_ctx *c, RasterArgs la, int loss, int n_shared, const FrameParams &fp)
 {
     la.cand_of_row = c->d_layer_rep; la.layers = c->d_layers;
-    if (n_shared == 3 && want_parents(c) && !(c->strategy & STRATEGY_NO_PARENTS)) {
+    if (use_parents(c, n_shared)) {
         const size_t need = (size_t)c->n_parents * c->n_tiles * (TILE_W * TILE_H);
         if (need > c->parents_cap) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -714,7 +722,7 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
     HIP_TRY(c, launch_fk(c->stream, cand, c->C, n_render, c->d_joint_fixed, c->d_joint_axes, PV, view_of, c->d_mvp, c->d_sums,
                          c->d_mask_lo, c->d_mask_hi, c->mask_words, c->d_qctr, queue_weights(c), c->d_tile_tris_lo, c->n_tiles));
     // weights of the shared links for the layer launch: with the second level in use it draws the last shared link only
-    const int lo_first = (n_shared == 3 && want_parents(c) && !(c->strategy & STRATEGY_NO_PARENTS)) ? 2 : 0;
+    const int lo_first = use_parents(c, n_shared) ? 2 : 0;
     HIP_TRY(c, launch_bounds(c->stream, c->C, fp, c->rp, n_render, n_shared, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->mask_words,
                              n_shared > 0 ? c->d_layer_of : nullptr, n_shared > 0 ? c->d_layer_rep : nullptr, queue_weights(c), c->d_tile_tris_lo, lo_first));
     return ROPE_OK;
