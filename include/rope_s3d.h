@@ -218,8 +218,10 @@ int rope_profile_eval(rope_ctx *ctx, int n_render, int loss, const int32_t *crop
  *   4  no second level of sharing (links 0-1 per distinct q0)
  *   8  large batches as one workgroup per (tile, candidate) pair instead of a queue of the pairs that have work
  *  16  always the raster kernels that can clip triangles at the near plane (by default only when the camera is within the
- *      robot's reach of it: they are several per cent slower, and without a triangle at the plane they draw the same image) */
-enum { ROPE_STRATEGY_NO_LAYERS = 1, ROPE_STRATEGY_NO_SPLIT = 2, ROPE_STRATEGY_NO_PARENTS = 4, ROPE_STRATEGY_NO_QUEUE = 8, ROPE_STRATEGY_CLIP_KERNELS = 16 };
+ *      robot's reach of it: they are several per cent slower, and without a triangle at the plane they draw the same image)
+ *  32  small batches: forward kinematics and screen boxes as a launch of their own instead of inside the split raster's workgroups */
+enum { ROPE_STRATEGY_NO_LAYERS = 1, ROPE_STRATEGY_NO_SPLIT = 2, ROPE_STRATEGY_NO_PARENTS = 4, ROPE_STRATEGY_NO_QUEUE = 8, ROPE_STRATEGY_CLIP_KERNELS = 16,
+       ROPE_STRATEGY_SEPARATE_GEOMETRY = 32 };
 int rope_set_strategy(rope_ctx *ctx, int flags);
 
 /* ---- Segmentation stage (robotpose/prediction/predict.py:94-98,416: the Matterport Mask R-CNN in front of the engine).

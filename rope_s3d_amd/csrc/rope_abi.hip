@@ -86,12 +86,17 @@ struct rope_ctx {
     int last_n_render = 0;
 
     // small batches: per-candidate tiles in global memory that split workgroups merge into
+    int *d_touched = nullptr;              // MODE_SPLIT_GEO: per (candidate, tile) the number of the pass that last drew into it
+    size_t touched_cap = 0;
+    int pass_id = 0;
+    bool mvp_valid = false;                // d_mvp holds the resident candidates' matrices (not after a pass that kept them in LDS)
     uint32_t *d_gtile = nullptr;
     size_t gtile_cap = 0;
     bool gtile_dirty = true;
     // MODE_SPLIT: busy workgroups aimed at per launch (one generation: 2 per CU), fewest / most per (tile, candidate), and the
     // workgroups per launch of the scoring pass that follows.  Measured at 160x90, 640x360 and 640x480 (tools/r02_split_tune.sh).
     int split_target = 512, split_min = 8, split_min_many = 3, split_cap = 64, score_target = 6144;
+    int geo_rows = 48;                     // most rows of a small batch whose raster workgroups do their own forward kinematics and boxes
     int layer_min_wg = 64;                 // fewest busy workgroups of a shared-layer launch for it to pay in a small batch (layers_pay)
     int strategy = 0;                          // STRATEGY_* bits (rope_set_strategy): launch structure only, never a result
     // large batches: queue of the (candidate, tile) pairs with something to draw, worked off by a grid that just fills the chip
@@ -187,6 +192,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
     if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 31;                     // tuning aid: rope_set_strategy's bits
     if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN")) c->split_min = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("ROPE_GEO_ROWS")) c->geo_rows = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ROPE_LAYER_MIN_WG")) c->layer_min_wg = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN_MANY")) c->split_min_many = std::max(1, std::min(64, std::atoi(e)));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -246,7 +252,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_touched, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
     for (void *p : ptrs)
@@ -735,9 +741,6 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    { int rc = enqueue_geometry(c, n_render, n_shared, fp, views); if (rc) return rc; }
-    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-    RasterArgs a = base_args(c, n_render);
     // Few candidates (descent pairs, flips): one workgroup per (tile, candidate) would leave most of the chip idle,
     // so the meshlets of each tile are split over several workgroups that merge into a tile in global memory.
     int split = 1;
@@ -750,6 +753,15 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         split = std::max(std::min(c->split_cap, c->split_target / std::max(1, c->C * busy_tiles)), std::min(floor_, c->split_cap));
         if (split < 2 || c->C * busy_tiles > 4 * c->split_target) split = 1;       // enough (tile, candidate) pairs to fill the chip whole
     }
+    // With the split, every workgroup can work out what it needs of the geometry itself — its candidate's six link matrices and
+    // the screen boxes of its own share of the meshlets: the fk + boxes launch (10 us of a 60 us evaluation, most of it the launch)
+    // goes.  (Not for the camera-pose path, whose rows name their own view matrices.)
+    // Up to a few dozen rows: from 64 on, the launch saved is no more than what the matrices cost when every share of every row repeats them.
+    const bool geo = split > 1 && !views && c->C <= c->geo_rows && !(c->strategy & STRATEGY_SEPARATE_GEOMETRY);
+    if (!geo) { int rc = enqueue_geometry(c, n_render, n_shared, fp, views); if (rc) return rc; }
+    c->mvp_valid = !geo;
+    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    RasterArgs a = base_args(c, n_render);
     if (split > 1) {
         const size_t need = (size_t)c->C * c->n_tiles * (TILE_W * TILE_H);
         if (need > c->gtile_cap) {
@@ -764,7 +776,20 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         c->gtile_dirty = true;
         RasterArgs sa = a;
         sa.split = split; sa.gtile = c->d_gtile;
-        HIP_TRY(c, launch_raster(MODE_SPLIT, loss, c->C, c->stream, fp, c->rp, sa, use_clip(c, views)));
+        if (geo) {
+            if ((size_t)c->C * c->n_tiles > c->touched_cap) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, realloc_dev(&c->d_touched, (size_t)256 * c->n_tiles));
+                HIP_TRY(c, hipMemset(c->d_touched, 0, (size_t)256 * c->n_tiles * sizeof(int)));
+                c->touched_cap = (size_t)256 * c->n_tiles;
+            }
+            sa.cand_q = c->cand_dev; sa.joint_fixed = c->d_joint_fixed; sa.joint_axes = c->d_joint_axes; sa.PV = c->d_PV;
+            sa.sums = c->d_sums;
+            sa.touched = c->d_touched;
+            sa.pass_id = ++c->pass_id;
+            a.touched = sa.touched; a.pass_id = sa.pass_id;
+        }
+        HIP_TRY(c, launch_raster(geo ? MODE_SPLIT_GEO : MODE_SPLIT, loss, c->C, c->stream, fp, c->rp, sa, use_clip(c, views)));
         a.gtile = c->d_gtile;
     }
     if (layers) {
@@ -1143,6 +1168,17 @@ extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
     if (!c) return ROPE_E_ARG;
     if (!mvp_out || C < 1 || C > c->C || n_render < 1 || n_render > ROPE_MAX_LINKS) ARG_FAIL(c, "rope_debug_mvp: bad arguments");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->mvp_valid) {
+        // the last pass worked the matrices out inside its raster workgroups: form them the way any other pass does
+        if (!c->cand_valid) ARG_FAIL(c, "rope_debug_mvp: no resident candidates");
+        const int keep = c->strategy;
+        c->strategy |= STRATEGY_SEPARATE_GEOMETRY;
+        const int rc = enqueue_geometry(c, n_render, 0, c->fp, false);
+        c->strategy = keep;
+        if (rc) return rc;
+        c->results_valid = false;                     // that launch cleared the sums
+        c->mvp_valid = true;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < C; i++)
         HIP_TRY(c, hipMemcpy(mvp_out + (size_t)i * n_render * 16, c->d_mvp + (size_t)i * ROPE_MAX_LINKS * 16,
@@ -1153,7 +1189,7 @@ extern "C" int rope_debug_mvp(rope_ctx *c, float *mvp_out, int C, int n_render)
 extern "C" int rope_set_strategy(rope_ctx *c, int flags)
 {
     if (!c) return ROPE_E_ARG;
-    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS | STRATEGY_NO_QUEUE | STRATEGY_CLIP_KERNELS)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
+    if (flags & ~(STRATEGY_NO_LAYERS | STRATEGY_NO_SPLIT | STRATEGY_NO_PARENTS | STRATEGY_NO_QUEUE | STRATEGY_CLIP_KERNELS | STRATEGY_SEPARATE_GEOMETRY)) ARG_FAIL(c, "rope_set_strategy: unknown flag");
     c->strategy = flags;
     return ROPE_OK;
 }

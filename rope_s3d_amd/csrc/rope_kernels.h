@@ -57,7 +57,7 @@ constexpr uint32_t D24_MAX = 16777215u;
 enum { SUM_CNT = 0, SUM_S1 = 1, SUM_AA = 2, SUM_AB = 3, SUM_BB = 4, SUM_LINK0 = 5 };
 static_assert(SUM_LINK0 + 3 * ROPE_MAX_LINKS == ROPE_SUM_WORDS, "sum layout");
 
-enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3, MODE_TABLE = 4, MODE_SPLIT = 5 };
+enum { MODE_SCORE = 0, MODE_DUMP = 1, MODE_COVER = 2, MODE_LAYER = 3, MODE_TABLE = 4, MODE_SPLIT = 5, MODE_SPLIT_GEO = 6 };
 
 struct FrameParams {
     int W, H, tiles_x, tiles_y;
@@ -77,7 +77,7 @@ struct FrameParams {
 #endif
 
 // Execution strategies that change the launch structure but never a result (rope_set_strategy)
-enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4, STRATEGY_NO_QUEUE = 8, STRATEGY_CLIP_KERNELS = 16 };
+enum { STRATEGY_NO_LAYERS = 1, STRATEGY_NO_SPLIT = 2, STRATEGY_NO_PARENTS = 4, STRATEGY_NO_QUEUE = 8, STRATEGY_CLIP_KERNELS = 16, STRATEGY_SEPARATE_GEOMETRY = 32 };
 
 struct RobotParams {
     const uint32_t *ml_header;            // n_meshlets x 8
@@ -120,6 +120,14 @@ struct RasterArgs {
     // their LDS tiles into gtile with atomicMin (MODE_SPLIT); score_gtile_kernel then scores and re-clears it
     int split;
     uint32_t *gtile;                      // C x n_tiles x (TILE_W*TILE_H) keys, 0xFFFFFFFF between passes
+    // MODE_SPLIT_GEO: MODE_SPLIT without the geometry launch in front — every workgroup works out its candidate's six link
+    // matrices itself (the chain is a few hundred double operations) and the screen boxes of its own share of the meshlets
+    // only, so the fk + boxes pass over all 1 450 meshlets, a launch of its own, disappears.  No masks then: a workgroup that
+    // lists a meshlet for its tile stamps touched[candidate x tiles + tile] with this pass's number, and score_gtile_kernel
+    // scores the tiles that carry it.
+    const double *cand_q, *joint_fixed, *joint_axes, *PV;
+    int *touched;
+    int pass_id;
 };
 
 hipError_t launch_fk(hipStream_t st, const double *cand, int C, int n_render, const double *joint_fixed,

@@ -520,7 +520,7 @@ __device__ static inline short4 meshlet_box(const FrameParams &fp, const RobotPa
     for (int ty = ty0; ty <= ty1; ty++)
         for (int tx = tx0; tx <= tx1; tx++) {
             const int t = ty * fp.tiles_x + tx;
-            atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
+            if (s_mask) atomicOr(&s_mask[l < n_shared ? 0 : 1][t >> 5], 1u << (t & 31));
             if (s_tris && l >= n_shared) atomicAdd(&s_tris[t], rp.ml_header[8 * m + 6] >> 16);
             if (s_tris_lo && l < n_shared && l >= lo_first) atomicAdd(&s_tris_lo[t], rp.ml_header[8 * m + 6] >> 16);
         }
@@ -815,11 +815,12 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
     const int n_render = ra.n_render;
     // camera-pose path: the candidate (= view x frame) names the frame whose target planes it is scored against
     const size_t frame = (MODE == MODE_SCORE && ra.frame_of) ? (size_t)ra.frame_of[row] : 0;
+    constexpr bool GEO = (MODE == MODE_SPLIT_GEO);      // forward kinematics and the share's screen boxes worked out here
     const size_t plane = (size_t)fp.W * fp.H;
     const uint64_t *__restrict__ tq = ra.tq ? ra.tq + frame * plane : nullptr;
     const float *__restrict__ t32 = ra.t32 ? ra.t32 + frame * plane : nullptr;
     const uint64_t *__restrict__ tl = ra.tl ? ra.tl + frame * plane * ROPE_MAX_LINKS : nullptr;
-    __shared__ uint32_t tile[TILE_W * TILE_H];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_W * TILE_H];
     __shared__ float s_mvp[ROPE_MAX_LINKS * 16];
     __shared__ uint16_t s_list[MAX_MESHLETS];
     __shared__ int s_count;
@@ -849,7 +850,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
     const size_t mw = (size_t)cand * ra.mask_words + (tile_id >> 5);
     // tiles of the shared links: kept for the layer's representative candidate only (bounds_kernel)
     const size_t mw_lo = (MODE != MODE_LAYER && ra.layer_of) ? (size_t)ra.layer_rep[ra.layer_of[cand]] * ra.mask_words + (tile_id >> 5) : mw;
-    const bool hit_lo = (ra.mask_lo[mw_lo] >> (tile_id & 31)) & 1u, hit_hi = (ra.mask_hi[mw] >> (tile_id & 31)) & 1u;
+    const bool hit_lo = GEO ? true : (ra.mask_lo[mw_lo] >> (tile_id & 31)) & 1u, hit_hi = GEO ? true : (ra.mask_hi[mw] >> (tile_id & 31)) & 1u;
     if (MODE == MODE_LAYER ? !hit_lo : !(hit_lo || hit_hi)) return;
     if (ROPE_SKIP(fp, 1)) return;
     // shared layer (links below l_begin, rendered once per distinct upstream pose) covering this tile
@@ -872,16 +873,40 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
 
     // --- tile initialisation (a copy of the layer tile, or "empty"), link matrices, and the list of meshlets whose
     // screen box meets this tile: all in one phase so that the global loads overlap
-    if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
+    if (GEO) {
+        // the candidate's link matrices, as fk_bounds_kernel forms them (same helpers, same order: same bits); the joint
+        // matrices side by side, one thread chains them; the doubles live in the tile's LDS, which is cleared afterwards
+        double (*s_A)[12] = reinterpret_cast<double (*)[12]>(tile);
+        double (*s_T)[12] = s_A + (ROPE_MAX_LINKS - 1);
+        if (tile_id == 0 && zme == 0 && tid < ROPE_SUM_WORDS) ra.sums[(size_t)cand * ROPE_SUM_WORDS + tid] = 0;      // score_gtile_kernel adds into them
+        if (tid < ROPE_MAX_LINKS - 1 && tid + 1 < n_render) joint_matrix(ra.cand_q[6 * cand + tid], tid, ra.joint_fixed, ra.joint_axes, s_A[tid]);
+        __syncthreads();
+        if (tid == 0) {
+            double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, N[12];
+            for (int l = 0; l < n_render; l++) {
+                if (l > 0) {
+                    aff_mul(T, s_A[l - 1], N);
+#pragma unroll
+                    for (int k = 0; k < 12; k++) T[k] = N[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 12; k++) s_T[l][k] = T[k];
+            }
+        }
+        __syncthreads();
+        if (tid < n_render * 16) s_mvp[tid] = mvp_element(ra.PV, s_T[tid >> 4], (tid >> 2) & 3, tid & 3);
+        __syncthreads();
+    } else if (tid < ROPE_MAX_LINKS * 16) s_mvp[tid] = ra.mvp[((size_t)cand * ROPE_MAX_LINKS) * 16 + tid];
     // the shared layer is not copied in: depth testing is a minimum, so it is merged where the tile is consumed
     for (int i = tid; i < TILE_W * TILE_H / 4; i += NTHREADS)
         reinterpret_cast<uint4 *>(tile)[i] = make_uint4(KEY_EMPTY, KEY_EMPTY, KEY_EMPTY, KEY_EMPTY);
     {
         const int m_begin = rp.link_first[ra.l_begin], m_end = rp.link_first[ra.l_end];
         const short4 *bb = ra.bounds + (size_t)cand * rp.n_meshlets;
-        for (int m = m_begin + tid; m < m_end; m += NTHREADS) {
-            if (zsplit > 1 && (m % zsplit) != zme) continue;       // this workgroup's share of the meshlets
-            const short4 b = bb[m];
+        // GEO: a thread per meshlet of this workgroup's share (m = first + k * zsplit) instead of a walk over all of them
+        for (int m = GEO ? m_begin + ((zme - m_begin % zsplit + zsplit) % zsplit) + tid * zsplit : m_begin + tid; m < m_end; m += GEO ? NTHREADS * zsplit : NTHREADS) {
+            if (!GEO && zsplit > 1 && (m % zsplit) != zme) continue;       // this workgroup's share of the meshlets
+            const short4 b = GEO ? meshlet_box(fp, rp, m, n_render, 0, s_mvp, nullptr) : bb[m];
             const int bx0 = b.x & 0x1FFF;
             if (bx0 <= b.y && bx0 <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
                 int pos = atomicAdd(&s_count, 1);
@@ -892,6 +917,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
     }
     __syncthreads();
     const int n_list = s_count;
+    if (GEO && n_list > 0 && tid == 0) ra.touched[(size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id] = ra.pass_id;      // for score_gtile_kernel
     const TileRect rc = {0, TILE_H - 1, 0, TILE_W / 4 - 1, 2};          // 4 groups x 16 rows per wave: measured best of 32x2, 8x8, 4x16, 2x32
     if (n_list == 0 && MODE != MODE_LAYER && !(MODE == MODE_TABLE && layer_tile)) {
         // nothing of this row lands in the tile: its sums stay those of the shared layer, or "empty"
@@ -1170,7 +1196,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
         }
         return;
     }
-    if (MODE == MODE_SPLIT) {
+    if (MODE == MODE_SPLIT || GEO) {
         // merge this workgroup's share into the candidate's tile in global memory (min is order-free)
         uint32_t *dst = ra.gtile + ((size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id) * (TILE_W * TILE_H);
         for (int i = tid; i < TILE_W * TILE_H; i += NTHREADS)
@@ -1226,7 +1252,8 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
     // would pile up there.  Rotating the tile index by a per-row hash spreads every tile over all XCDs.
     const int n_tiles_all = fp.tiles_x * fp.tiles_y;
     const int tile_id = (int)((blockIdx.x + ((blockIdx.y * 0x9E3779B1u) >> 12)) % (unsigned)n_tiles_all);
-    raster_tile<LOSS, MODE, CLIP>(fp, rp, ra, (int)blockIdx.y, tile_id, (MODE == MODE_SPLIT) ? (int)blockIdx.z : 0, (MODE == MODE_SPLIT) ? (int)gridDim.z : 1);
+    constexpr bool SHARES = (MODE == MODE_SPLIT || MODE == MODE_SPLIT_GEO);
+    raster_tile<LOSS, MODE, CLIP>(fp, rp, ra, (int)blockIdx.y, tile_id, SHARES ? (int)blockIdx.z : 0, SHARES ? (int)gridDim.z : 1);
 }
 
 // Large batches: the (candidate, tile) pairs that have anything to draw, taken from a queue by a grid that just fills the
@@ -1320,7 +1347,9 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
     const int tid = threadIdx.x, tile_id = blockIdx.x, cand = blockIdx.y;
     const size_t mw = (size_t)cand * ra.mask_words + (tile_id >> 5);
-    if (!(((ra.mask_lo[mw] | ra.mask_hi[mw]) >> (tile_id & 31)) & 1u)) return;      // MODE_SPLIT left this tile alone
+    if (ra.touched) {                                                                  // MODE_SPLIT_GEO stamps the tiles it drew into
+        if (ra.touched[(size_t)cand * (fp.tiles_x * fp.tiles_y) + tile_id] != ra.pass_id) return;
+    } else if (!(((ra.mask_lo[mw] | ra.mask_hi[mw]) >> (tile_id & 31)) & 1u)) return;      // MODE_SPLIT left this tile alone
     const size_t frame = ra.frame_of ? (size_t)ra.frame_of[cand] : 0, plane = (size_t)fp.W * fp.H;
     const uint64_t *__restrict__ tq = ra.tq ? ra.tq + frame * plane : nullptr;
     const float *__restrict__ t32 = ra.t32 ? ra.t32 + frame * plane : nullptr;
@@ -1613,11 +1642,12 @@ hipError_t launch_fk_bounds(hipStream_t st, const double *cand, int C, const Fra
 hipError_t launch_raster(int mode, int loss, int rows, hipStream_t st, const FrameParams &fp, const RobotParams &rp,
                          const RasterArgs &a, bool clip)
 {
-    dim3 grid(fp.tiles_x * fp.tiles_y, rows, mode == MODE_SPLIT ? a.split : 1);
+    dim3 grid(fp.tiles_x * fp.tiles_y, rows, (mode == MODE_SPLIT || mode == MODE_SPLIT_GEO) ? a.split : 1);
     if (mode == MODE_DUMP) launch_one<ROPE_LOSS_DEPTH, MODE_DUMP>(grid, st, fp, rp, a, clip);
     else if (mode == MODE_COVER) launch_one<ROPE_LOSS_DEPTH, MODE_COVER>(grid, st, fp, rp, a, clip);
     else if (mode == MODE_TABLE) launch_one<ROPE_LOSS_LOOKUP, MODE_TABLE>(grid, st, fp, rp, a, clip);
     else if (mode == MODE_SPLIT) launch_one<ROPE_LOSS_DEPTH, MODE_SPLIT>(grid, st, fp, rp, a, clip);
+    else if (mode == MODE_SPLIT_GEO) launch_one<ROPE_LOSS_DEPTH, MODE_SPLIT_GEO>(grid, st, fp, rp, a, clip);
     else if (mode == MODE_LAYER) {
         if (loss == ROPE_LOSS_DEPTH) launch_one<ROPE_LOSS_DEPTH, MODE_LAYER>(grid, st, fp, rp, a, clip);
         else if (loss == ROPE_LOSS_FULL) launch_one<ROPE_LOSS_FULL, MODE_LAYER>(grid, st, fp, rp, a, clip);

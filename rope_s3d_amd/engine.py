@@ -329,7 +329,7 @@ class Engine:
         self._check(self._lib.rope_debug_mvp(self._ctx, _p(out), int(C_), int(n_render)), 'rope_debug_mvp')
         return out
 
-    NO_LAYERS, NO_SPLIT, NO_PARENTS, NO_QUEUE, CLIP_KERNELS = 1, 2, 4, 8, 16
+    NO_LAYERS, NO_SPLIT, NO_PARENTS, NO_QUEUE, CLIP_KERNELS, SEPARATE_GEOMETRY = 1, 2, 4, 8, 16, 32
 
     def set_strategy(self, flags: int):
         """rope_set_strategy: launch structure only (shared layers / small-batch split / second sharing level off);

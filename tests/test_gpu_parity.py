@@ -122,12 +122,17 @@ def test_small_batch_split_does_not_change_results(scene):
     for n_c in (1, 2, 6):
         for loss, n in ((eng.LOSS_FULL, 6), (eng.LOSS_FULL, 4), (eng.LOSS_DEPTH, 6)):
             err_a, sums_a, bi_a, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
-            e.set_strategy(e.NO_SPLIT)
-            try:
-                err_b, sums_b, bi_b, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
-            finally:
-                e.set_strategy(0)
-            assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b
+            # one workgroup per tile; and forward kinematics + screen boxes as a launch of their own instead of inside the split
+            # raster's workgroups (the default for small batches)
+            for flag in (e.NO_SPLIT, e.SEPARATE_GEOMETRY):
+                e.set_strategy(flag)
+                try:
+                    err_b, sums_b, bi_b, _ = e.eval(cand[:n_c], n, loss, want_sums=True)
+                finally:
+                    e.set_strategy(0)
+                assert np.array_equal(sums_a, sums_b) and np.array_equal(err_a.view(np.uint64), err_b.view(np.uint64)) and bi_a == bi_b, flag
+            err_c, sums_c, bi_c, _ = e.eval(cand[:n_c], n, loss, want_sums=True)       # buffers and stamps came back usable
+            assert np.array_equal(sums_a, sums_c) and bi_a == bi_c
             ref = o.eval(cand[:n_c], loss, n, tq, t32, None, flags, threads=4)
             assert np.array_equal(err_a.view(np.uint64), ref.view(np.uint64))
 
