@@ -757,7 +757,9 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     // the screen boxes of its own share of the meshlets: the fk + boxes launch (10 us of a 60 us evaluation, most of it the launch)
     // goes.  (Not for the camera-pose path, whose rows name their own view matrices.)
     // Up to a few dozen rows: from 64 on, the launch saved is no more than what the matrices cost when every share of every row repeats them.
-    const bool geo = split > 1 && !views && c->C <= c->geo_rows && !(c->strategy & STRATEGY_SEPARATE_GEOMETRY);
+    // And on frames of a few tiles only (the Predictor's 160x90 is two): on a 25-tile frame two thirds of the workgroups belong to tiles
+    // the robot does not reach — the masks of the separate launch let them leave at once, here each would do the matrices first.
+    const bool geo = split > 1 && !views && c->C <= c->geo_rows && c->n_tiles <= 4 && !(c->strategy & STRATEGY_SEPARATE_GEOMETRY);
     if (!geo) { int rc = enqueue_geometry(c, n_render, n_shared, fp, views); if (rc) return rc; }
     c->mvp_valid = !geo;
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
