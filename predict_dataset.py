@@ -71,6 +71,7 @@ def run(args):
         pool = PredictorPool(n_pred - 1, ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
                              do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
         pool.predictors.insert(0, am)
+        pool._tune()
 
     lo, hi = shard_range(ds.length, rank, world)
     out = np.zeros((hi - lo, 6))
