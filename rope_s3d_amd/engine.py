@@ -142,6 +142,7 @@ class Engine:
         self.W = self.H = 0
         self.n_links = 0
         self.n_candidates = 0
+        self._strategy = 0            # last value given to rope_set_strategy (the ROPE_STRATEGY environment default is the library's own)
 
     def close(self):
         if getattr(self, '_ctx', None) is not None and self._ctx.value:
@@ -335,6 +336,7 @@ class Engine:
         """rope_set_strategy: launch structure only (shared layers / small-batch split / second sharing level off);
         results are bit-identical for every value."""
         self._check(self._lib.rope_set_strategy(self._ctx, int(flags)), 'rope_set_strategy')
+        self._strategy = int(flags)
 
     def debug_skip(self, mask: int):
         """Kernel-phase ablation; only the profiling build of the library has it (tools/build_variants.py profile)."""

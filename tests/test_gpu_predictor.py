@@ -459,6 +459,12 @@ def test_predictor_pool_equals_one_predictor(synth):
         assert np.array_equal(pool.run_many(colors, depths, [DEFAULT_CAMERA_POSE] * 10), want)
     assert np.array_equal(pool.run_many(colors[:2], depths[:2]), want[:2]) and pool.run_many([], []).shape == (0, 6)
     assert pool.evaluations > 0 and len(pool) == 3
+    # many Predictors on one GPU take the geometry launch of its own back (PredictorPool._tune): the same angles
+    assert all(q.renderer.engine._strategy == 0 for q in pool.predictors)
+    pool.THROUGHPUT_FROM = 2
+    pool._tune()
+    assert all(q.renderer.engine._strategy == q.renderer.engine.SEPARATE_GEOMETRY for q in pool.predictors)
+    assert np.array_equal(pool.run_many(colors, depths), want)
 
 
 @pytest.mark.parametrize('native', [True, False])
