@@ -87,6 +87,11 @@ int rope_set_camera(rope_ctx *ctx, const double *PV, int W, int H, double znear,
  *   link_flags 8 bytes: bit0 link present in the target, bit1 ">5 % of mask has depth" (predict.py:495) */
 int rope_set_target(rope_ctx *ctx, const uint64_t *tq, const float *t32, const uint8_t *link_flags);
 
+/* The float32 plane ROPE_LOSS_TSWEEP reads, when it is not the lookup plane: TensorSweep compares against the WHOLE target depth
+ * (predict.py:358-363, `self._tgt_depth`), the Lookup stage against the depth under the lookup links (predict.py:165-169).  Call after
+ * rope_set_target (which forgets it); NULL goes back to the one plane. */
+int rope_set_target_tsweep(rope_ctx *ctx, const float *t32_full);
+
 /* Host only (no context): the packing rope_set_target expects.  depth n float64 metres (NaN, inf and values <= 0 count
  * as "no depth"), mask_bits n bytes (bit l = link l's mask) or NULL -> out n uint64: Q32 depth, round half even,
  * clipped to 2^39-1, mask bits at 40..47. */
@@ -156,13 +161,15 @@ int rope_eval_views(rope_ctx *ctx, const double *PV, int K, int n_render, int lo
  * lists (stages.py:128-178); the target must have been set with rope_set_target (full loss masks + lookup plane).
  * Decisions follow the reference operation for operation, quirks included (SFlip's aliasing and its comparison
  * outside the endpoint loop, ISweep's stale base error, Descent's error history of the last joint only); the
- * not-a-knot cubic of interp1d(kind='cubic') (predict.py:310) is solved directly.  TensorSweep is not part of
- * either list and is not offered here (drive it with rope_eval and ROPE_LOSS_TSWEEP). */
+ * not-a-knot cubic of interp1d(kind='cubic') (predict.py:310) is solved directly.  TensorSweep (in neither list, but a stage the
+ * reference defines) is ROPE_STAGE_TSWEEP. */
 enum {
     ROPE_STAGE_LOOKUP = 0,   /* stages.py:16-24   predict.py:165-171 */
     ROPE_STAGE_DESCENT = 1,  /* stages.py:92-119  predict.py:173-230 */
     ROPE_STAGE_SFLIP = 2,    /* stages.py:30-41   predict.py:232-281 */
-    ROPE_STAGE_ISWEEP = 3    /* stages.py:50-69   predict.py:283-338 */
+    ROPE_STAGE_ISWEEP = 3,   /* stages.py:50-69   predict.py:283-338 */
+    ROPE_STAGE_TSWEEP = 4    /* stages.py:71-90   predict.py:340-373: `count` divisions over `joints`, `range` as InterpolativeSweep; scored
+                                with ROPE_LOSS_TSWEEP against the plane of rope_set_target_tsweep (the *- sign kept: the largest mean*std wins) */
 };
 
 typedef struct rope_stage {
@@ -202,6 +209,32 @@ typedef struct rope_predict_args {
  *   trace_out   n_stages x 6 doubles, the angles after every stage; may be NULL
  *   n_evals     candidate poses rendered and scored (lookup rows included); may be NULL */
 int rope_predict(rope_ctx *ctx, const rope_predict_args *args, double *angles_out, double *trace_out, int64_t *n_evals);
+
+/* ---- Many frames at once.  The reference predicts a dataset frame by frame (predict_dataset.py:43-44), each frame a chain of ~25
+ * dependent render batches of 2-26 poses (predict.py:173-338).  Frames are independent (fresh state per frame, predict.py:144-148),
+ * so B of them can walk the stage list in lockstep: every step then is ONE device batch holding the rows of all B frames, each row
+ * scored against its own frame's target.
+ *
+ * rope_set_targets: the targets of n_frames frames, resident until replaced (they share buffers with rope_set_frames: one or the other).
+ *   tq          n_frames planes H x W uint64 (as rope_set_target)
+ *   t32         n_frames planes H x W float32 (lookup planes) or NULL
+ *   t32_tsweep  n_frames planes H x W float32 for ROPE_LOSS_TSWEEP (rope_set_target_tsweep) or NULL
+ *   link_flags  n_frames x 8 bytes (as rope_set_target)
+ * rope_eval_targets: R candidate rows, row i scored against frame frame_of[i]'s target -> err_out[i]; loss DEPTH / FULL / LOOKUP
+ *   (crop required) / TSWEEP.  Every error has the bits rope_eval gives with that frame as the single target.
+ * rope_lookup_score_targets: the stored table of rope_lookup_build against every resident target in one pass: per frame the first
+ *   argmin row and (optionally) its score; scores_out: n_frames x table rows or NULL.  Same bits as rope_lookup_score per frame. */
+int rope_set_targets(rope_ctx *ctx, int n_frames, const uint64_t *tq, const float *t32, const float *t32_tsweep, const uint8_t *link_flags);
+int rope_eval_targets(rope_ctx *ctx, const double *cand, const int32_t *frame_of, int R, int n_render, int loss, const int32_t *crop,
+                      double *err_out);
+int rope_lookup_score_targets(rope_ctx *ctx, int32_t *best_idx, double *best_score, double *scores_out);
+
+/* rope_predict for the n_frames resident targets of rope_set_targets, in lockstep: the same stage list, limits and camera for all of
+ * them (args as rope_predict; lookup_angles_live must be NULL — the table aliasing makes frames depend on their order).  A frame
+ * that leaves a Descent stage early simply contributes no rows to the later batches of that stage.  Every frame's angles and trace
+ * are those of rope_predict on that frame alone.
+ *   angles_out  n_frames x 6;  trace_out  n_frames x n_stages x 6 or NULL;  n_evals  total poses rendered and scored, or NULL */
+int rope_predict_batch(rope_ctx *ctx, const rope_predict_args *args, int n_frames, double *angles_out, double *trace_out, int64_t *n_evals);
 
 /* Device-side per-candidate link matrices of the last eval (C x n_render x 16 float32), for tests. */
 int rope_debug_mvp(rope_ctx *ctx, float *mvp_out, int C, int n_render);

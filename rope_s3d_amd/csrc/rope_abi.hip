@@ -141,6 +141,34 @@ struct rope_ctx {
     int ftotal_cap = 0;
     bool ftotal_valid[5] = {false, false, false, false, false};   // per loss kind: d_ftotal[loss] holds the frames' "nothing rendered" totals
 
+    // batched prediction (rope_set_targets / rope_eval_targets / rope_lookup_score_targets): the targets of n_targets frames.  The
+    // packed planes and the lookup planes live in d_ftq / d_ft32, which the camera-pose path's frames use as well: setting one
+    // kind unsets the other.
+    int n_targets = 0;
+    bool targets_t32 = false, targets_ts = false;
+    float *d_fts32 = nullptr;               // TensorSweep planes (the whole target depth as float32), when given
+    size_t fts_cap = 0;
+    LinkFlags *d_fflags = nullptr;          // per frame
+    int fflags_cap = 0;
+    uint64_t *d_tg_total[4] = {nullptr, nullptr, nullptr, nullptr};   // per loss: n_targets x SUM_WORDS "nothing rendered" totals
+    uint64_t *d_tg_empty = nullptr;         // scratch: n_targets x n_tiles x SUM_WORDS
+    int tg_total_cap = 0;
+    size_t tg_empty_cap = 0;
+    bool tg_total_valid[4] = {false, false, false, false};
+    int tg_crop[4][4] = {};
+    int32_t *d_frame_of = nullptr, *h_frame_of = nullptr, *d_frame_of_host = nullptr;   // rows' frame indices: device copy / mapped host memory (small batches)
+    int frame_of_cap = 0;
+    const int32_t *frame_of_dev = nullptr;
+    // the stored lookup table against all targets
+    float *d_tg_t32c = nullptr;
+    uint64_t *d_tg_ltotal = nullptr;
+    double *d_tg_scores = nullptr, *d_tg_best = nullptr;
+    size_t tg_t32c_cap = 0, tg_scores_cap = 0;
+    int tg_best_cap = 0;
+    // single target: the float32 plane ROPE_LOSS_TSWEEP reads when it is not the lookup plane (rope_set_target_tsweep)
+    float *d_t32ts = nullptr;
+    bool have_t32ts = false;
+
     // single-pose render scratch
     uint32_t *d_key = nullptr;
     float *d_depth = nullptr;
@@ -189,7 +217,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
     if (!c) return ROPE_E_NOMEM;
     c->device = device;
     if (const char *e = std::getenv("ROPE_SPLIT_TARGET")) c->split_target = std::max(1, std::atoi(e));     // tuning aid
-    if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 31;                     // tuning aid: rope_set_strategy's bits
+    if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 63;                     // tuning aid: rope_set_strategy's bits
     if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN")) c->split_min = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("ROPE_GEO_ROWS")) c->geo_rows = std::max(0, std::atoi(e));
@@ -204,6 +232,8 @@ extern "C" int rope_create(rope_ctx **out, int device)
         hipHostGetDevicePointer((void **)&c->d_err_host, c->h_err, 0) != hipSuccess ||
         hipHostMalloc((void **)&c->h_cand, 6 * rope_ctx::HOST_ERR_ROWS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_cand_host, c->h_cand, 0) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_frame_of, rope_ctx::HOST_ERR_ROWS * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_frame_of_host, c->h_frame_of, 0) != hipSuccess ||
         hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&c->d_qctr, 2 * QUEUE_COUNTERS * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_best_err, sizeof(double)) != hipSuccess ||
@@ -254,12 +284,14 @@ extern "C" void rope_destroy(rope_ctx *c)
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
                     c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_touched, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
-                    c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3]};
+                    c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3], c->d_fts32, c->d_fflags, c->d_tg_total[0], c->d_tg_total[1], c->d_tg_total[2],
+                    c->d_tg_total[3], c->d_tg_empty, c->d_frame_of, c->d_tg_t32c, c->d_tg_ltotal, c->d_tg_scores, c->d_tg_best, c->d_t32ts};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_cand) (void)hipHostFree(c->h_cand);
+    if (c->h_frame_of) (void)hipHostFree(c->h_frame_of);
     if (c->h_vstage) (void)hipHostFree(c->h_vstage);
     if (c->h_vsums) (void)hipHostFree(c->h_vsums);
     if (c->h_copy) (void)hipHostFree(c->h_copy);
@@ -374,12 +406,15 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
         // the context has no camera, no target and no frames until this call has gone through
         c->have_camera = false;
         c->have_target = false;
+        c->have_t32ts = false;
         c->n_frames = 0;
+        c->n_targets = 0;
         c->C = 0;
         c->cand_valid = c->results_valid = false;
         const size_t n = (size_t)W * H;
         HIP_TRY(c, realloc_dev(&c->d_tq, n));
         HIP_TRY(c, realloc_dev(&c->d_t32, n));
+        HIP_TRY(c, realloc_dev(&c->d_t32ts, n));
         HIP_TRY(c, realloc_dev(&c->d_key, n));
         HIP_TRY(c, realloc_dev(&c->d_depth, n));
         HIP_TRY(c, realloc_dev(&c->d_ids, n));
@@ -419,9 +454,25 @@ extern "C" int rope_set_target(rope_ctx *c, const uint64_t *tq, const float *t32
     if (t32) { rc = copy_h2d_staged(c, c->d_t32, t32, n * sizeof(float)); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_t32 = (t32 != nullptr);
+    c->have_t32ts = false;
     std::memcpy(c->lf.f, link_flags, 8);
     c->have_target = true;
     c->target_version++;
+    return ROPE_OK;
+}
+
+extern "C" int rope_set_target_tsweep(rope_ctx *c, const float *t32_full)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!c->have_target) ARG_FAIL(c, "rope_set_target_tsweep: call rope_set_target first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (t32_full) {
+        const int rc = copy_h2d_staged(c, c->d_t32ts, t32_full, (size_t)c->fp.W * c->fp.H * sizeof(float));
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_t32ts = (t32_full != nullptr);
+    c->empty_version[ROPE_LOSS_TSWEEP] = 0;         // that loss's "nothing rendered" sums belong to the other plane
     return ROPE_OK;
 }
 
@@ -493,7 +544,6 @@ static bool use_clip(const rope_ctx *c, bool views = false)
     if (c->strategy & STRATEGY_CLIP_KERNELS) return true;
     return views ? c->clip_views : near_plane_in_reach(c, c->h_PV);
 }
-
 static int ensure_capacity(rope_ctx *c, int C)
 {
     if (C <= c->cap) return ROPE_OK;
@@ -526,7 +576,7 @@ static int ensure_capacity(rope_ctx *c, int C)
     return ROPE_OK;
 }
 
-static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group);
+static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group, const int32_t *frame_of = nullptr);
 
 extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
 {
@@ -534,7 +584,9 @@ extern "C" int rope_candidates_upload(rope_ctx *c, const double *cand, int C)
     return upload_candidates(c, cand, C, true);
 }
 
-static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
+// frame_of (rope_eval_targets): the frame every row is scored against; rows only share a layer inside one frame (a layer
+// carries loss sums, and those belong to a target)
+static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group, const int32_t *frame_of)
 {
     if (!cand || C < 1 || C > 65535) ARG_FAIL(c, "rope_candidates_upload: need 1 <= C <= 65535");
     for (size_t i = 0; i < 6 * (size_t)C; i++)
@@ -546,29 +598,46 @@ static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group)
     if (C <= rope_ctx::HOST_ERR_ROWS) {            // nothing is in flight (synchronised above): the kernels of the next pass read it in place
         std::memcpy(c->h_cand, cand, 6 * (size_t)C * sizeof(double));
         c->cand_dev = c->d_cand_host;
+        if (frame_of) { std::memcpy(c->h_frame_of, frame_of, (size_t)C * sizeof(int32_t)); c->frame_of_dev = c->d_frame_of_host; }
     } else {
         std::memcpy(c->h_stage, cand, 6 * (size_t)C * sizeof(double));
         HIP_TRY(c, hipMemcpyAsync(c->d_cand, c->h_stage, 6 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, c->stream));
         c->cand_dev = c->d_cand;
+        if (frame_of) {
+            if (C > c->frame_of_cap) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->frame_of_cap = 0;
+                HIP_TRY(c, realloc_dev(&c->d_frame_of, (size_t)std::max(C, 1024)));
+                c->frame_of_cap = std::max(C, 1024);
+            }
+            // pageable source: the copy has read it when the call returns
+            HIP_TRY(c, hipMemcpyAsync(c->d_frame_of, frame_of, (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            c->frame_of_dev = c->d_frame_of;
+        }
     }
+    if (!frame_of) c->frame_of_dev = nullptr;
     // group candidates whose first two joint angles are bit-identical: their base_link, link_1_s and
     // link_2_l transforms are the same bits, so those links are rasterised once per group (a "layer")
     c->n_layers = C;                               // "no sharing" unless the grouping below finds some
     if (group && C >= 8) {
-        struct Key { uint64_t a, b; int idx; };
+        struct Key { uint64_t a, b; int idx, frame; };
         std::vector<Key> keys((size_t)C);
         for (int i = 0; i < C; i++) {
             std::memcpy(&keys[i].a, &cand[6 * (size_t)i], 8);
             std::memcpy(&keys[i].b, &cand[6 * (size_t)i + 1], 8);
             keys[i].idx = i;
+            keys[i].frame = frame_of ? frame_of[i] : 0;
         }
-        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.idx < y.idx); });
+        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) {
+            return x.frame != y.frame ? x.frame < y.frame : (x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.idx < y.idx));
+        });
         std::vector<int32_t> layer_of((size_t)C), layer_rep, parent_of, parent_rep;
         for (int i = 0; i < C; i++) {
-            if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) {
+            const bool new_frame = i == 0 || keys[i].frame != keys[i - 1].frame;
+            if (new_frame || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) {
                 layer_rep.push_back(keys[i].idx);
                 // layers come out sorted by q0: a new q0 opens a new parent, represented by this layer's own candidate
-                if (i == 0 || keys[i].a != keys[i - 1].a) parent_rep.push_back(keys[i].idx);
+                if (new_frame || keys[i].a != keys[i - 1].a) parent_rep.push_back(keys[i].idx);
                 parent_of.push_back((int32_t)parent_rep.size() - 1);
             }
             layer_of[keys[i].idx] = (int32_t)layer_rep.size() - 1;
@@ -609,7 +678,8 @@ static int check_eval_args(rope_ctx *c, int n_render, int loss, const int32_t *c
     if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "eval: n_render out of range");
     if (loss < 0 || loss > 3) ARG_FAIL(c, "eval: unknown loss");
     if (!c->have_target) ARG_FAIL(c, "eval: no target set");
-    if ((loss == ROPE_LOSS_LOOKUP || loss == ROPE_LOSS_TSWEEP) && !c->have_t32) ARG_FAIL(c, "eval: this loss needs the float32 target plane");
+    if (loss == ROPE_LOSS_LOOKUP && !c->have_t32) ARG_FAIL(c, "eval: this loss needs the float32 target plane");
+    if (loss == ROPE_LOSS_TSWEEP && !c->have_t32 && !c->have_t32ts) ARG_FAIL(c, "eval: this loss needs a float32 target plane");
     fp = c->fp;
     n_pix = (double)fp.W * fp.H;
     if (loss == ROPE_LOSS_LOOKUP) {
@@ -621,11 +691,14 @@ static int check_eval_args(rope_ctx *c, int n_render, int loss, const int32_t *c
     return ROPE_OK;
 }
 
+// the float32 plane a loss reads: TensorSweep takes the whole target depth when it was given (rope_set_target_tsweep)
+static const float *t32_plane(const rope_ctx *c, int loss) { return (loss == ROPE_LOSS_TSWEEP && c->have_t32ts) ? c->d_t32ts : c->d_t32; }
+
 static int ensure_empty(rope_ctx *c, int loss, const FrameParams &fp)
 {
     const int cr[4] = {fp.r0, fp.r1, fp.c0, fp.c1};
     if (c->empty_version[loss] == c->target_version && std::memcmp(cr, c->empty_crop[loss], sizeof cr) == 0) return ROPE_OK;
-    HIP_TRY(c, launch_empty(loss, c->stream, fp, c->d_tq, c->d_t32, nullptr, c->d_empty[loss], c->d_total[loss]));
+    HIP_TRY(c, launch_empty(loss, c->stream, fp, c->d_tq, t32_plane(c, loss), nullptr, c->d_empty[loss], c->d_total[loss]));
     c->empty_version[loss] = c->target_version;
     std::memcpy(c->empty_crop[loss], cr, sizeof cr);
     return ROPE_OK;
@@ -716,6 +789,8 @@ static uint32_t *queue_weights(const rope_ctx *c)
 }
 
 // forward kinematics + link matrices + screen boxes + tile masks (+ cleared sums) of the resident candidates
+enum { EVAL_SINGLE = 0, EVAL_VIEWS = 1, EVAL_TARGETS = 2 };    // one target / camera-pose path (a view and a frame per row) / a frame per row
+
 static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const FrameParams &fp, bool views)
 {
     const double *PV = views ? c->dv_PV : c->d_PV, *cand = views ? c->dv_cand : c->cand_dev;
@@ -735,8 +810,10 @@ static int enqueue_geometry(rope_ctx *c, int n_render, int n_shared, const Frame
 }
 
 static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &fp, double n_pix,
-                        hipEvent_t *ev /* 5 events or nullptr */, bool views = false)
+                        hipEvent_t *ev /* 5 events or nullptr */, int mode = EVAL_SINGLE)
 {
+    const bool views = mode == EVAL_VIEWS, targets = mode == EVAL_TARGETS;
+    const float *tg_t32 = !targets ? nullptr : ((loss == ROPE_LOSS_TSWEEP && c->targets_ts) ? c->d_fts32 : (c->targets_t32 ? c->d_ft32 : nullptr));
     const bool layers = !views && want_layers(c) && layers_pay(c) && !(c->strategy & STRATEGY_NO_LAYERS);
     const int n_shared = layers ? std::min(3, n_render) : 0;
     if (layers) { int rc = ensure_layers(c); if (rc) return rc; }
@@ -796,11 +873,13 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     }
     if (layers) {
         RasterArgs la = a;
-        la.layer_sums = c->d_layer_sums; la.tq = c->d_tq; la.t32 = c->d_t32;
+        la.layer_sums = c->d_layer_sums; la.tq = c->d_tq; la.t32 = t32_plane(c, loss);
+        if (targets) { la.tq = c->d_ftq; la.t32 = tg_t32; la.frame_of = c->frame_of_dev; }
         { int rc = enqueue_layers(c, la, loss, n_shared, fp); if (rc) return rc; }
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
-    a.tq = c->d_tq; a.t32 = c->d_t32; a.empty_sums = c->d_empty[loss & 3]; a.sums = c->d_sums;
+    a.tq = c->d_tq; a.t32 = t32_plane(c, loss); a.sums = c->d_sums;
+    if (targets) { a.tq = c->d_ftq; a.t32 = tg_t32; a.frame_of = c->frame_of_dev; }
     if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->dv_frame_of; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     if (split > 1) {
@@ -818,8 +897,12 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
     c->err_on_host = c->C <= rope_ctx::HOST_ERR_ROWS;
-    HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf,
-                               c->err_on_host ? c->d_err_host : c->d_err));
+    if (targets)                                   // every row against its own frame's totals and link flags; no argmin (rows of many frames)
+        HIP_TRY(c, launch_finalize_frames(c->stream, c->d_sums, c->d_tg_total[loss], c->frame_of_dev, c->d_fflags, c->C, loss, n_render, n_pix,
+                                          c->err_on_host ? c->d_err_host : c->d_err));
+    else
+        HIP_TRY(c, launch_finalize(c->stream, c->d_sums, c->d_total[loss], c->C, loss, n_render, n_pix, c->lf,
+                                   c->err_on_host ? c->d_err_host : c->d_err));
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     c->last_n_render = n_render;
     c->results_valid = true;
@@ -1077,6 +1160,7 @@ extern "C" int rope_set_frames(rope_ctx *c, int n_frames, const double *q, const
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->h_fq.assign(q, q + 6 * (size_t)n_frames);
     c->n_frames = n_frames;
+    c->n_targets = 0;                             // the planes are the camera-pose path's now
     for (bool &v : c->ftotal_valid) v = false;
     return ROPE_OK;
 }
@@ -1141,7 +1225,7 @@ extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_rende
                                     ftotal + (size_t)i * ROPE_SUM_WORDS));
         c->ftotal_valid[loss] = true;
     }
-    rc = enqueue_eval(c, n_render, loss, c->fp, (double)plane, nullptr, true);
+    rc = enqueue_eval(c, n_render, loss, c->fp, (double)plane, nullptr, EVAL_VIEWS);
     if (rc) return rc;
     const size_t n_sums = (size_t)C * ROPE_SUM_WORDS, n_tot = (size_t)N * ROPE_SUM_WORDS;
     if (n_sums + n_tot > c->vsums_cap) {
@@ -1162,6 +1246,128 @@ extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_rende
                 const bool live = w < SUM_LINK0 || (links && w < SUM_LINK0 + 3 * n_render);
                 o = live ? o + total[(size_t)i * ROPE_SUM_WORDS + w] : 0;      // modulo 2^64, as the kernel's deltas are
             }
+    return ROPE_OK;
+}
+
+// ---- batched prediction: the targets of many frames resident at once, every row of a batch scored against its own frame's
+extern "C" int rope_set_targets(rope_ctx *c, int n_frames, const uint64_t *tq, const float *t32, const float *t32_tsweep, const uint8_t *link_flags)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!c->have_camera) ARG_FAIL(c, "rope_set_targets: call rope_set_camera first (image size)");
+    if (!tq || !link_flags || n_frames < 1 || n_frames > 65535) ARG_FAIL(c, "rope_set_targets: need 1 <= n_frames <= 65535, tq and link_flags");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_targets = 0;
+    c->n_frames = 0;                              // d_ftq / d_ft32 are shared with the camera-pose path's frames
+    const size_t plane = (size_t)c->fp.W * c->fp.H, n = plane * (size_t)n_frames;
+    if (n > c->frames_cap) { c->frames_cap = 0; HIP_TRY(c, realloc_dev(&c->d_ftq, n)); c->frames_cap = n; }
+    int rc = copy_h2d_staged(c, c->d_ftq, tq, n * sizeof(uint64_t));
+    if (rc) return rc;
+    if (t32) {
+        if (n > c->frames_t32_cap) { c->frames_t32_cap = 0; HIP_TRY(c, realloc_dev(&c->d_ft32, n)); c->frames_t32_cap = n; }
+        rc = copy_h2d_staged(c, c->d_ft32, t32, n * sizeof(float));
+        if (rc) return rc;
+    }
+    if (t32_tsweep) {
+        if (n > c->fts_cap) { c->fts_cap = 0; HIP_TRY(c, realloc_dev(&c->d_fts32, n)); c->fts_cap = n; }
+        rc = copy_h2d_staged(c, c->d_fts32, t32_tsweep, n * sizeof(float));
+        if (rc) return rc;
+    }
+    if (n_frames > c->fflags_cap) { c->fflags_cap = 0; HIP_TRY(c, realloc_dev(&c->d_fflags, (size_t)n_frames)); c->fflags_cap = n_frames; }
+    static_assert(sizeof(LinkFlags) == 8, "link flags travel as 8 bytes per frame");
+    rc = copy_h2d_staged(c, c->d_fflags, link_flags, 8 * (size_t)n_frames);
+    if (rc) return rc;
+    if (n_frames > c->tg_total_cap) {
+        c->tg_total_cap = 0;
+        for (int k = 0; k < 4; k++) HIP_TRY(c, realloc_dev(&c->d_tg_total[k], (size_t)n_frames * ROPE_SUM_WORDS));
+        HIP_TRY(c, realloc_dev(&c->d_tg_ltotal, (size_t)n_frames * ROPE_SUM_WORDS));
+        c->tg_total_cap = n_frames;
+    }
+    const size_t empties = (size_t)n_frames * c->n_tiles * ROPE_SUM_WORDS;
+    if (empties > c->tg_empty_cap) { c->tg_empty_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_empty, empties)); c->tg_empty_cap = empties; }
+    if (n_frames > c->tg_best_cap) { c->tg_best_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_best, 2 * (size_t)n_frames)); c->tg_best_cap = n_frames; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->targets_t32 = (t32 != nullptr);
+    c->targets_ts = (t32_tsweep != nullptr);
+    for (bool &v : c->tg_total_valid) v = false;
+    for (bool &v : c->ftotal_valid) v = false;
+    c->n_targets = n_frames;
+    return ROPE_OK;
+}
+
+// "nothing rendered" totals of every resident target for this loss (and crop)
+static int ensure_target_totals(rope_ctx *c, int loss, const FrameParams &fp)
+{
+    const int cr[4] = {fp.r0, fp.r1, fp.c0, fp.c1};
+    if (c->tg_total_valid[loss] && std::memcmp(cr, c->tg_crop[loss], sizeof cr) == 0) return ROPE_OK;
+    const float *t32 = (loss == ROPE_LOSS_TSWEEP && c->targets_ts) ? c->d_fts32 : (c->targets_t32 ? c->d_ft32 : nullptr);
+    HIP_TRY(c, launch_empty(loss, c->stream, fp, c->d_ftq, t32, nullptr, c->d_tg_empty, c->d_tg_total[loss], c->n_targets));
+    c->tg_total_valid[loss] = true;
+    std::memcpy(c->tg_crop[loss], cr, sizeof cr);
+    return ROPE_OK;
+}
+
+extern "C" int rope_eval_targets(rope_ctx *c, const double *cand, const int32_t *frame_of, int R, int n_render, int loss, const int32_t *crop,
+                                 double *err_out)
+{
+    if (!c) return ROPE_E_ARG;
+    if (!c->have_robot || !c->have_camera) ARG_FAIL(c, "rope_eval_targets: robot and camera must be set first");
+    if (c->n_targets < 1) ARG_FAIL(c, "rope_eval_targets: no targets set (rope_set_targets)");
+    if (!cand || !frame_of || !err_out || R < 1) ARG_FAIL(c, "rope_eval_targets: bad arguments");
+    if (n_render < 1 || n_render > c->n_links) ARG_FAIL(c, "rope_eval_targets: n_render out of range");
+    if (loss < 0 || loss > 3) ARG_FAIL(c, "rope_eval_targets: unknown loss");
+    if (loss == ROPE_LOSS_LOOKUP && !c->targets_t32) ARG_FAIL(c, "rope_eval_targets: this loss needs the targets' float32 planes");
+    if (loss == ROPE_LOSS_TSWEEP && !c->targets_t32 && !c->targets_ts) ARG_FAIL(c, "rope_eval_targets: this loss needs float32 planes");
+    for (int i = 0; i < R; i++)
+        if (frame_of[i] < 0 || frame_of[i] >= c->n_targets) ARG_FAIL(c, "rope_eval_targets: frame index outside the resident targets");
+    FrameParams fp = c->fp;
+    double n_pix = (double)fp.W * fp.H;
+    if (loss == ROPE_LOSS_LOOKUP) {
+        if (!crop) ARG_FAIL(c, "rope_eval_targets: lookup loss needs a crop");
+        if (crop[0] < 0 || crop[1] >= fp.H || crop[0] > crop[1] || crop[2] < 0 || crop[3] >= fp.W || crop[2] > crop[3]) ARG_FAIL(c, "rope_eval_targets: crop outside the image");
+        fp.r0 = crop[0]; fp.r1 = crop[1]; fp.c0 = crop[2]; fp.c1 = crop[3];
+        n_pix = (double)(crop[1] - crop[0] + 1) * (double)(crop[3] - crop[2] + 1);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_target_totals(c, loss, fp);
+    if (rc) return rc;
+    for (int lo = 0; lo < R; lo += MAX_ROWS) {
+        const int n = std::min(MAX_ROWS, R - lo);
+        rc = upload_candidates(c, cand + 6 * (size_t)lo, n, true, frame_of + lo);
+        if (rc) return rc;
+        rc = enqueue_eval(c, n_render, loss, fp, n_pix, nullptr, EVAL_TARGETS);
+        // the rows are scored against the frames' targets: nothing here is a result of the single-target calls
+        c->cand_valid = c->results_valid = false;
+        if (rc) return rc;
+        if (!c->err_on_host) HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_err, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::memcpy(err_out + lo, c->err_on_host ? c->h_err : c->h_stage, (size_t)n * sizeof(double));
+    }
+    return ROPE_OK;
+}
+
+extern "C" int rope_lookup_score_targets(rope_ctx *c, int32_t *best_idx, double *best_score, double *scores_out)
+{
+    if (!c) return ROPE_E_ARG;
+    if (c->table_C < 1) ARG_FAIL(c, "rope_lookup_score_targets: no table built");
+    if (c->n_targets < 1 || !c->targets_t32) ARG_FAIL(c, "rope_lookup_score_targets: needs targets with their float32 planes (rope_set_targets)");
+    if (!best_idx) ARG_FAIL(c, "rope_lookup_score_targets: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    FrameParams fp = c->fp;
+    fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
+    const size_t crop_px = (size_t)(fp.r1 - fp.r0 + 1) * (size_t)(fp.c1 - fp.c0 + 1), N = (size_t)c->n_targets;
+    if (N * crop_px > c->tg_t32c_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->tg_t32c_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_t32c, N * crop_px)); c->tg_t32c_cap = N * crop_px; }
+    if (N * c->table_C > c->tg_scores_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->tg_scores_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_scores, N * c->table_C)); c->tg_scores_cap = N * c->table_C; }
+    HIP_TRY(c, launch_table_score_frames(c->stream, fp, c->d_trect, c->d_toff, c->d_tpack, c->table_C, c->d_ft32, c->n_targets, c->d_tg_t32c, c->d_tg_ltotal,
+                                         c->d_tg_scores, c->d_tg_best));
+    std::vector<double> best(2 * N);
+    HIP_TRY(c, hipMemcpyAsync(best.data(), c->d_tg_best, 2 * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_tg_scores, N * c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t f = 0; f < N; f++) {
+        best_idx[f] = (int32_t)best[2 * f + 1];
+        if (best_score) best_score[f] = best[2 * f];
+    }
     return ROPE_OK;
 }
 

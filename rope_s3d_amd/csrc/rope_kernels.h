@@ -22,6 +22,15 @@ namespace rope {
 #ifndef ROPE_MIN_WAVES_FULL
 #define ROPE_MIN_WAVES_FULL 6               // the link counts are packed fields (score_pixel): fits 80 VGPRs without spills
 #endif
+// The instantiations that can clip at the near plane: ONE workgroup per CU (3 waves per SIMD, up to 168 VGPRs), so that they
+// compile without scratch.  At 6 waves per SIMD (80 VGPRs) they spill 65-69 VGPRs and 61-63 SGPRs into 200-216 bytes of scratch
+// per lane, and the layer-queue kernel of that build, raster_queue_kernel<DEPTH, LAYER, CLIP>, gave sums that differed from run
+// to run on a scene without a single triangle near the plane (round 3: tools/dbg_clip.py, profiles/r03_clip_fault.txt; same
+// source, no scratch: deterministic and bit-equal to the plain kernels).  They are the rare path — a camera within the robot's
+// reach of the near plane — and correctness there is worth more than occupancy.
+#ifndef ROPE_MIN_WAVES_CLIP
+#define ROPE_MIN_WAVES_CLIP 3
+#endif
 constexpr int TILE_W = ROPE_TILE_W;
 constexpr int TILE_H = ROPE_TILE_H;
 constexpr int NWAVES = ROPE_NWAVES;       // waves per workgroup of the raster kernel
@@ -109,9 +118,9 @@ struct RasterArgs {
     const int32_t *base_rep;              // parent row -> its candidate: a parent tile exists only where that candidate's mask_lo says so
     uint32_t *layers;                     // n_layers x n_tiles x (TILE_W*TILE_H) keys
     uint64_t *layer_sums;                 // n_layers x n_tiles x ROPE_SUM_WORDS: loss sums of the layer alone
-    const uint64_t *tq; const float *t32; const uint64_t *empty_sums;
-    // camera-pose path: planes of all frames back to back (frame stride H*W; tl: 6 per-link planes per frame,
-    // bit 40 = link mask, bits 0..38 = masked target depth) and each candidate's frame index
+    const uint64_t *tq; const float *t32;
+    // camera-pose path and batches over several frames' targets: planes of all frames back to back (frame stride H*W; tl: 6
+    // per-link planes per frame, bit 40 = link mask, bits 0..38 = masked target depth) and each candidate's frame index
     const uint64_t *tl;
     const int32_t *frame_of;
     uint64_t *sums; uint32_t *key_out; uint8_t *cover;
@@ -162,8 +171,10 @@ hipError_t launch_layer_queue(int loss, int rows, int workgroups, hipStream_t st
                               const RasterArgs &a, uint32_t *items, size_t segment, int *counters, const uint32_t *tile_tris_lo, bool clip);
 // scores what a MODE_SPLIT launch merged into a.gtile; `slices` row slices per tile (a divisor of TILE_H)
 hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, const FrameParams &fp, const RasterArgs &a);
+// "nothing rendered" sums of n_frames frames (planes back to back): empty_sums n_frames x n_tiles x SUM_WORDS of scratch,
+// total n_frames x SUM_WORDS
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,
-                        uint64_t *empty_sums, uint64_t *total);
+                        uint64_t *empty_sums, uint64_t *total, int n_frames = 1);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err /* C + 2: errors, best error, best index */);
 // the stored lookup table keeps of every row the rectangle that holds its samples: dense rows (C x ch x cw) -> rects / offs /
@@ -174,6 +185,16 @@ hipError_t launch_table_pack(hipStream_t st, int cw, int ch, const float *table,
 // t32c: scratch of crop_h x crop_w floats (the cropped target, rebuilt by every call); total: ROPE_SUM_WORDS words of scratch
 hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
                               const float *packed, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums);
+// batches over several frames' targets (rope_eval_targets / rope_lookup_score_targets)
+hipError_t launch_finalize_frames(hipStream_t st, uint64_t *sums, const uint64_t *totals /* frames x SUM_WORDS */, const int32_t *frame_of,
+                                  const LinkFlags *flags /* per frame, device */, int C, int loss, int n_render, double n_pix, double *err /* C */);
+// first argmin of n_sets sets of C doubles: best[2 k] error, best[2 k + 1] index
+hipError_t launch_argmin_sets(hipStream_t st, const double *err, int C, int n_sets, double *best);
+// the stored table against the float32 planes of n_frames frames: t32c n_frames x crop floats of scratch, totals n_frames x
+// SUM_WORDS of scratch, scores n_frames x C, best n_frames x 2 (score, row)
+hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
+                                     const float *packed, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,
+                                     double *scores, double *best);
 hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);
 
 }  // namespace rope

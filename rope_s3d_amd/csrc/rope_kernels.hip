@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "rope_kernels.h"
 
 namespace rope {
@@ -357,27 +359,32 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
 
 // Sums of every tile when nothing is rendered into it; the raster kernel adds
 // (actual - empty) for the tiles it touches, finalize adds the frame total back.
+// grid = (tiles, frames): the planes of frame f start f planes (tl: 6 f planes) into the arrays
 template <int LOSS>
 __global__ void __launch_bounds__(NTHREADS)
 empty_tile_kernel(FrameParams fp, const uint64_t *__restrict__ tq, const float *__restrict__ t32, const uint64_t *__restrict__ tl,
-                  uint64_t *__restrict__ empty_sums /* n_tiles x SUM_WORDS */)
+                  uint64_t *__restrict__ empty_sums /* frames x n_tiles x SUM_WORDS */)
 {
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
     if (threadIdx.x < ROPE_SUM_WORDS) lds_sums[threadIdx.x] = 0;
     __syncthreads();
+    const size_t plane = (size_t)fp.W * fp.H, f = blockIdx.y;
     int tile = blockIdx.x, tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq, t32, tl, lds_sums, TileRect{0, TILE_H - 1, 0, TILE_W / 4 - 1, 5});
+    score_tile<LOSS, false>(nullptr, nullptr, ty * TILE_H, tx * TILE_W, fp, ROPE_MAX_LINKS, tq ? tq + f * plane : nullptr, t32 ? t32 + f * plane : nullptr,
+                            tl ? tl + f * plane * ROPE_MAX_LINKS : nullptr, lds_sums, TileRect{0, TILE_H - 1, 0, TILE_W / 4 - 1, 5});
     __syncthreads();
-    if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[(size_t)tile * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
+    if (threadIdx.x < ROPE_SUM_WORDS) empty_sums[((size_t)f * gridDim.x + tile) * ROPE_SUM_WORDS + threadIdx.x] = lds_sums[threadIdx.x];
 }
 
+// one workgroup per frame
 __global__ void total_tiles_kernel(const uint64_t *__restrict__ empty_sums, int n_tiles, uint64_t *__restrict__ total)
 {
     int k = threadIdx.x;
     if (k >= ROPE_SUM_WORDS) return;
+    const uint64_t *e = empty_sums + (size_t)blockIdx.x * n_tiles * ROPE_SUM_WORDS;
     uint64_t t = 0;
-    for (int i = 0; i < n_tiles; i++) t += empty_sums[(size_t)i * ROPE_SUM_WORDS + k];
-    total[k] = t;
+    for (int i = 0; i < n_tiles; i++) t += e[(size_t)i * ROPE_SUM_WORDS + k];
+    total[(size_t)blockIdx.x * ROPE_SUM_WORDS + k] = t;
 }
 
 // ------------------------------------------------------------------ raster -----
@@ -813,8 +820,10 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
                                             const int tile_id, const int zme, const int zsplit)
 {
     const int n_render = ra.n_render;
-    // camera-pose path: the candidate (= view x frame) names the frame whose target planes it is scored against
-    const size_t frame = (MODE == MODE_SCORE && ra.frame_of) ? (size_t)ra.frame_of[row] : 0;
+    const int cand = (MODE == MODE_LAYER) ? ra.cand_of_row[row] : row;
+    // camera-pose path and batches over several frames' targets: the candidate names the frame whose target planes it is scored
+    // against (a shared layer: its representative candidate's frame — layers never span frames, upload_candidates)
+    const size_t frame = ((MODE == MODE_SCORE || MODE == MODE_LAYER) && ra.frame_of) ? (size_t)ra.frame_of[cand] : 0;
     constexpr bool GEO = (MODE == MODE_SPLIT_GEO);      // forward kinematics and the share's screen boxes worked out here
     const size_t plane = (size_t)fp.W * fp.H;
     const uint64_t *__restrict__ tq = ra.tq ? ra.tq + frame * plane : nullptr;
@@ -833,7 +842,6 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
     __shared__ uint64_t lds_sums[ROPE_SUM_WORDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cand = (MODE == MODE_LAYER) ? ra.cand_of_row[row] : row;
     const int tx = tile_id % fp.tiles_x, ty = tile_id / fp.tiles_x;
     const int col0 = tx * TILE_W, row0 = ty * TILE_H;
     // tile rectangle in GL window pixel coordinates (y up), clamped to the image
@@ -1244,7 +1252,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
 // MODE_DUMP : write the tile's keys to a full-frame key image (single-pose render).
 // MODE_COVER: set cover[pixel] = 1 where anything was drawn (crop search).
 template <int LOSS, int MODE, bool CLIP>
-__global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(NTHREADS, CLIP ? ROPE_MIN_WAVES_CLIP : ((LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD))
 raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 {
     // Workgroups go to the 8 XCDs round-robin by linear id, i.e. by (row * n_tiles + blockIdx.x) mod 8: with an even
@@ -1261,7 +1269,7 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 // launch over all of them spends a fifth of a millisecond starting workgroups that leave at once.  score_queue_kernel
 // builds the queue.  A workgroup asks for its next pair while it works on the current one.
 template <int LOSS, int MODE, bool CLIP>
-__global__ void __launch_bounds__(NTHREADS, (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(NTHREADS, CLIP ? ROPE_MIN_WAVES_CLIP : ((LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD))
 raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, size_t segment,
                     int *__restrict__ counters /* [1] next ticket, [2 + k] pairs queued in class k */)
 {
@@ -1380,11 +1388,15 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
 
 // One workgroup: the crop of the target plane as one contiguous array laid out like the crop (no index arithmetic on the
 // image per sample later), and the sums of |T| over it.
+// grid = frames: frame f's plane starts f planes into t32, its crop f crops into t32c, its totals f x ROPE_SUM_WORDS into total
 __global__ void __launch_bounds__(1024)
 crop_total_kernel(FrameParams fp, const float *__restrict__ t32, float *__restrict__ t32c, uint64_t *__restrict__ total /* ROPE_SUM_WORDS */)
 {
     __shared__ uint64_t lds[4];
     const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1, n = cw * ch;
+    t32 += (size_t)blockIdx.x * fp.W * fp.H;
+    t32c += (size_t)blockIdx.x * n;
+    total += (size_t)blockIdx.x * ROPE_SUM_WORDS;
     if (threadIdx.x < 4) lds[threadIdx.x] = 0;
     __syncthreads();
     uint64_t s[ROPE_SUM_WORDS];
@@ -1446,17 +1458,11 @@ table_pack_kernel(int cw, int ch, const float *__restrict__ table, ushort4 *__re
     }
 }
 
-__global__ void __launch_bounds__(256)
-table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned long long *__restrict__ offs, const float *__restrict__ packed,
-                   const float *__restrict__ t32c, const uint64_t *__restrict__ total, uint64_t *__restrict__ sums)
+// One table row against one cropped target: lds[0..3] += sum over the row's rectangle of |T - D| minus sum of |T| (words S1, AA, AB,
+// BB), modulo 2^64 (the true value of total + s is not negative).  lds cleared and the workgroup synchronised by the caller.
+__device__ static inline void table_row_delta(const ushort4 rc, const float4 *__restrict__ row4, const float *__restrict__ t32c, int cw, uint64_t *lds)
 {
-    __shared__ uint64_t lds[4];
-    const ushort4 rc = rects[blockIdx.x];
     const int r0 = rc.x, c0 = rc.y, w = rc.w, m = (int)rc.z * (int)rc.w;
-    const float4 *row4 = reinterpret_cast<const float4 *>(packed + offs[blockIdx.x]);
-    if (threadIdx.x < 4) lds[threadIdx.x] = 0;
-    __syncthreads();
-    // s = sum over the rectangle of |T - D| minus sum of |T|, modulo 2^64 (the true value of total + s is not negative)
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
     const float inv_w = 1.0f / (float)max(w, 1);
@@ -1484,11 +1490,57 @@ table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned lon
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds[k], (unsigned long long)v);
     }
+}
+
+__global__ void __launch_bounds__(256)
+table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned long long *__restrict__ offs, const float *__restrict__ packed,
+                   const float *__restrict__ t32c, const uint64_t *__restrict__ total, uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t lds[4];
+    if (threadIdx.x < 4) lds[threadIdx.x] = 0;
     __syncthreads();
+    table_row_delta(rects[blockIdx.x], reinterpret_cast<const float4 *>(packed + offs[blockIdx.x]), t32c, cw, lds);
+    __syncthreads();
+    const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
     if (threadIdx.x < ROPE_SUM_WORDS) {
         uint64_t v = 0;
         for (int k = 0; k < 4; k++) if ((int)threadIdx.x == words[k]) v = total[words[k]] + lds[k];
         sums[(size_t)blockIdx.x * ROPE_SUM_WORDS + threadIdx.x] = v;
+    }
+}
+
+__device__ static inline double mean_std_parts(const uint64_t *s, double N, double &m1);
+
+// The same for the targets of many frames (rope_lookup_score_targets): grid = (table rows, frame chunks); a workgroup takes its
+// row against the cropped target of every frame of its chunk — the row's values come from HBM once and from the cache afterwards —
+// and writes the finished lookup score (finalize_one's steps for ROPE_LOSS_LOOKUP on the same sums: same bits) to
+// scores[frame x rows + row].
+__global__ void __launch_bounds__(256)
+table_score_frames_kernel(int cw, int crop_px, const ushort4 *__restrict__ rects, const unsigned long long *__restrict__ offs,
+                          const float *__restrict__ packed, const float *__restrict__ t32c /* frames x crop_px */,
+                          const uint64_t *__restrict__ totals /* frames x ROPE_SUM_WORDS */, int n_frames, double n_pix,
+                          double *__restrict__ scores)
+{
+    __shared__ uint64_t lds[4];
+    const ushort4 rc = rects[blockIdx.x];
+    const float4 *row4 = reinterpret_cast<const float4 *>(packed + offs[blockIdx.x]);
+    const int per = (n_frames + (int)gridDim.y - 1) / (int)gridDim.y, f_lo = (int)blockIdx.y * per, f_hi = min(f_lo + per, n_frames);
+    for (int f = f_lo; f < f_hi; f++) {
+        if (threadIdx.x < 4) lds[threadIdx.x] = 0;
+        __syncthreads();
+        table_row_delta(rc, row4, t32c + (size_t)f * crop_px, cw, lds);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t s[ROPE_SUM_WORDS];
+#pragma unroll
+            for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
+            const uint64_t *total = totals + (size_t)f * ROPE_SUM_WORDS;
+            s[SUM_S1] = total[SUM_S1] + lds[0]; s[SUM_AA] = total[SUM_AA] + lds[1]; s[SUM_AB] = total[SUM_AB] + lds[2]; s[SUM_BB] = total[SUM_BB] + lds[3];
+            double m1;
+            const double sd = mean_std_parts(s, n_pix, m1);
+            scores[(size_t)f * gridDim.x + blockIdx.x] = m1 * sd;
+        }
+        __syncthreads();
     }
 }
 
@@ -1541,6 +1593,57 @@ finalize_only_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ t
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) err[i] = finalize_one(sums, total_empty, i, loss, n_render, n_pix, lf);
+}
+
+// batches over several frames' targets: every row adds its own frame's "nothing rendered" totals and reads its frame's link flags
+__global__ void __launch_bounds__(256)
+finalize_frames_kernel(uint64_t *__restrict__ sums, const uint64_t *__restrict__ totals /* frames x SUM_WORDS */, const int32_t *__restrict__ frame_of,
+                       const LinkFlags *__restrict__ flags /* per frame */, int C, int loss, int n_render, double n_pix, double *__restrict__ err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const int f = frame_of[i];
+    err[i] = finalize_one(sums, totals + (size_t)f * ROPE_SUM_WORDS, i, loss, n_render, n_pix, flags[f]);
+}
+
+// first index of the smallest of err[0..C) (a NaN never beats a number; all NaN: index 0), one workgroup per set of C values:
+// best[2 set] = the error, best[2 set + 1] = the index — finalize_argmin_kernel's rule
+__global__ void __launch_bounds__(1024)
+argmin_sets_kernel(const double *__restrict__ err_all, int C, double *__restrict__ best)
+{
+    __shared__ double s_e[16];
+    __shared__ int s_i[16];
+    const double *err = err_all + (size_t)blockIdx.x * C;
+    double be = __builtin_inf();
+    int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        const double e = err[i];
+        if (e < be || (e == be && i < bi) || (bi == 0x7FFFFFFF && !(e != e))) { be = e; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double oe = __shfl_xor(be, off, 64);
+        int oi = __shfl_xor(bi, off, 64);
+        if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_e[wave] = be; s_i[wave] = bi; }
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = blockDim.x >> 6;
+        be = lane < nw ? s_e[lane] : __builtin_inf();
+        bi = lane < nw ? s_i[lane] : 0x7FFFFFFF;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            double oe = __shfl_xor(be, off, 64);
+            int oi = __shfl_xor(bi, off, 64);
+            if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
+        }
+        if (lane == 0) {
+            best[2 * (size_t)blockIdx.x] = (bi == 0x7FFFFFFF) ? err[0] : be;
+            best[2 * (size_t)blockIdx.x + 1] = (bi == 0x7FFFFFFF) ? 0.0 : (double)bi;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -1705,9 +1808,9 @@ hipError_t launch_score_gtile(int loss, int rows, int slices, hipStream_t st, co
 }
 
 hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const uint64_t *tq, const float *t32, const uint64_t *tl,
-                        uint64_t *empty_sums, uint64_t *total)
+                        uint64_t *empty_sums, uint64_t *total, int n_frames)
 {
-    dim3 grid(fp.tiles_x * fp.tiles_y);
+    dim3 grid(fp.tiles_x * fp.tiles_y, n_frames);
     switch (loss) {
     case ROPE_LOSS_DEPTH: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_DEPTH>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
     case ROPE_LOSS_FULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_FULL>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
@@ -1715,7 +1818,7 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
     case ROPE_LOSS_CAMFULL: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_CAMFULL>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
     default: hipLaunchKernelGGL(empty_tile_kernel<ROPE_LOSS_TSWEEP>, grid, dim3(NTHREADS), 0, st, fp, tq, t32, tl, empty_sums); break;
     }
-    hipLaunchKernelGGL(total_tiles_kernel, dim3(1), dim3(64), 0, st, empty_sums, fp.tiles_x * fp.tiles_y, total);
+    hipLaunchKernelGGL(total_tiles_kernel, dim3(n_frames), dim3(64), 0, st, empty_sums, fp.tiles_x * fp.tiles_y, total);
     return hipGetLastError();
 }
 
@@ -1726,6 +1829,33 @@ hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total
     if (big) hipLaunchKernelGGL(finalize_only_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, total_empty, C, loss, n_render, n_pix, lf, err);
     hipLaunchKernelGGL(finalize_argmin_kernel, dim3(1), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, sums, total_empty, C, loss,
                        n_render, n_pix, lf, err, big);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_frames(hipStream_t st, uint64_t *sums, const uint64_t *totals, const int32_t *frame_of, const LinkFlags *flags,
+                                  int C, int loss, int n_render, double n_pix, double *err)
+{
+    hipLaunchKernelGGL(finalize_frames_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, totals, frame_of, flags, C, loss, n_render, n_pix, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmin_sets(hipStream_t st, const double *err, int C, int n_sets, double *best)
+{
+    hipLaunchKernelGGL(argmin_sets_kernel, dim3(n_sets), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, err, C, best);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
+                                     const float *packed, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,
+                                     double *scores, double *best)
+{
+    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
+    hipLaunchKernelGGL(crop_total_kernel, dim3(n_frames), dim3(1024), 0, st, fp, t32, t32c, totals);
+    // enough workgroups to fill the chip when the table is small; otherwise a row meets every frame in one workgroup
+    const int chunks = std::max(1, std::min(n_frames, (4096 + C - 1) / C));
+    hipLaunchKernelGGL(table_score_frames_kernel, dim3(C, chunks), dim3(256), 0, st, cw, cw * ch, rects, offs, packed, t32c, totals, n_frames,
+                       (double)cw * (double)ch, scores);
+    hipLaunchKernelGGL(argmin_sets_kernel, dim3(n_frames), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, scores, C, best);
     return hipGetLastError();
 }
 

@@ -22,10 +22,11 @@ ABI_SYMBOLS = (
     'rope_candidates_upload', 'rope_eval_resident', 'rope_sync', 'rope_results_download', 'rope_eval',
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_set_strategy',
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
-    'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act')
+    'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
+    'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch')
 
 
-STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP = 0, 1, 2, 3
+STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP, STAGE_TSWEEP = 0, 1, 2, 3, 4
 
 
 class StageDesc(C.Structure):
@@ -99,6 +100,11 @@ def load_library(path: str = None):
     lib.rope_seg_bias_act.argtypes = [vp, vp, vp, C.c_int64, i32, C.c_int64, i32, vp]
     lib.rope_set_frames.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.rope_set_target_tsweep.argtypes = [vp, vp]
+    lib.rope_set_targets.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.rope_eval_targets.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.rope_lookup_score_targets.argtypes = [vp, vp, vp, vp]
+    lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -200,6 +206,78 @@ class Engine:
             lf[:len(link_flags)] = link_flags
         self._check(self._lib.rope_set_target(self._ctx, _p(tq), _p(t32), _p(lf)), 'rope_set_target')
 
+    def set_target_tsweep(self, t32_full: np.ndarray = None):
+        """The float32 plane ROPE_LOSS_TSWEEP reads (the whole target depth) when it is not the lookup plane; None: the one plane."""
+        if t32_full is not None:
+            t32_full = np.ascontiguousarray(t32_full, np.float32)
+            if t32_full.shape != (self.H, self.W):
+                raise ValueError("float32 target plane has the wrong shape")
+        self._check(self._lib.rope_set_target_tsweep(self._ctx, _p(t32_full)), 'rope_set_target_tsweep')
+
+    # -- many frames at once --------------------------------------------------------------------
+    def set_targets(self, tq: np.ndarray, t32: np.ndarray = None, link_flags: np.ndarray = None, t32_tsweep: np.ndarray = None):
+        """The targets of N frames resident at once (rope_set_targets): tq (N,H,W) uint64, t32 / t32_tsweep (N,H,W) float32 or None,
+        link_flags (N,8) uint8."""
+        tq = np.ascontiguousarray(tq, np.uint64)
+        n = len(tq)
+        if tq.shape != (n, self.H, self.W):
+            raise ValueError(f"target planes must be {(n, self.H, self.W)}, got {tq.shape}")
+        planes = []
+        for a in (t32, t32_tsweep):
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float32)
+                if a.shape != tq.shape:
+                    raise ValueError("float32 target planes have the wrong shape")
+            planes.append(a)
+        lf = np.zeros((n, 8), np.uint8)
+        if link_flags is not None:
+            lf[:] = np.asarray(link_flags, np.uint8).reshape(n, 8)
+        self._check(self._lib.rope_set_targets(self._ctx, n, _p(tq), _p(planes[0]), _p(planes[1]), _p(lf)), 'rope_set_targets')
+        self.n_targets = n
+
+    def eval_targets(self, cand, frame_of, n_render: int, loss: int, crop=None) -> np.ndarray:
+        """Row i of `cand` scored against the resident target frame_of[i] -> errors (R,)."""
+        cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
+        fo = np.ascontiguousarray(frame_of, np.int32).reshape(-1)
+        if len(fo) != len(cand):
+            raise ValueError("one frame index per row")
+        crop_a = np.ascontiguousarray(crop, np.int32) if crop is not None else None
+        err = np.empty(len(cand), np.float64)
+        self._check(self._lib.rope_eval_targets(self._ctx, _p(cand), _p(fo), len(cand), int(n_render), int(loss), _p(crop_a), _p(err)), 'rope_eval_targets')
+        return err
+
+    def lookup_score_targets(self, want_scores: bool = False):
+        """The stored table against every resident target -> (scores (N, rows) or None, first-argmin row per frame, its score per frame)."""
+        n = self.n_targets
+        scores = np.empty((n, self._table_rows), np.float64) if want_scores else None
+        bi, be = np.empty(n, np.int32), np.empty(n, np.float64)
+        self._check(self._lib.rope_lookup_score_targets(self._ctx, _p(bi), _p(be), _p(scores)), 'rope_lookup_score_targets')
+        return scores, bi, be
+
+    def _predict_args(self, stages, limits, camera_pose, min_ang_inc, lookup_angles, lookup_crop, use_table, speculate, lookup_live):
+        arr = stages if isinstance(stages, C.Array) else (StageDesc * len(stages))(*stages)
+        limits = np.ascontiguousarray(limits, np.float64).reshape(6, 2)
+        cam = np.ascontiguousarray(camera_pose, np.float64).reshape(6)
+        inc = np.ascontiguousarray(min_ang_inc, np.float64).reshape(6)
+        grid = np.ascontiguousarray(lookup_angles, np.float64).reshape(-1, 6) if lookup_angles is not None else None
+        crop = np.ascontiguousarray(lookup_crop, np.int32).reshape(4) if lookup_crop is not None else None
+        if lookup_live is not None:                  # the reference's table aliasing: edited in place by the library
+            if grid is None or lookup_live.shape != grid.shape or lookup_live.dtype != np.float64 or not lookup_live.flags.c_contiguous:
+                raise ValueError("lookup_live must be a C-contiguous float64 array of the grid's shape")
+        a = PredictArgs(arr, len(arr), int(speculate), _p(limits), _p(cam), _p(inc), _p(grid), 0 if grid is None else len(grid),
+                        1 if use_table else 0, _p(crop), _p(lookup_live))
+        return a, (arr, limits, cam, inc, grid, crop, lookup_live)          # the arrays the struct points into stay alive with the tuple
+
+    def predict_batch(self, stages, limits, camera_pose, min_ang_inc, lookup_angles=None, lookup_crop=None, use_table=False,
+                      speculate: int = 3):
+        """rope_predict_batch: the stage machine over all resident targets in lockstep.
+        -> (angles (N, 6), trace (N, n_stages, 6), candidate poses evaluated)."""
+        a, keep = self._predict_args(stages, limits, camera_pose, min_ang_inc, lookup_angles, lookup_crop, use_table, speculate, None)
+        n = self.n_targets
+        out, trace, cnt = np.empty((n, 6)), np.empty((n, a.n_stages, 6)), C.c_int64()
+        self._check(self._lib.rope_predict_batch(self._ctx, C.byref(a), n, _p(out), _p(trace), C.byref(cnt)), 'rope_predict_batch')
+        return out, trace, int(cnt.value)
+
     # -- evaluation ---------------------------------------------------------------------------
     def upload_candidates(self, cand: np.ndarray):
         cand = np.ascontiguousarray(cand, np.float64).reshape(-1, 6)
@@ -267,18 +345,8 @@ class Engine:
                 speculate: int = 3, lookup_live: np.ndarray = None):
         """rope_predict: the whole stage machine of one frame in one call.  `stages` = StageDesc array (or list).
         -> (angles (6,), trace (n_stages, 6), candidate poses evaluated)."""
-        arr = stages if isinstance(stages, C.Array) else (StageDesc * len(stages))(*stages)
-        limits = np.ascontiguousarray(limits, np.float64).reshape(6, 2)
-        cam = np.ascontiguousarray(camera_pose, np.float64).reshape(6)
-        inc = np.ascontiguousarray(min_ang_inc, np.float64).reshape(6)
-        grid = np.ascontiguousarray(lookup_angles, np.float64).reshape(-1, 6) if lookup_angles is not None else None
-        crop = np.ascontiguousarray(lookup_crop, np.int32).reshape(4) if lookup_crop is not None else None
-        if lookup_live is not None:                  # the reference's table aliasing: edited in place by the library
-            if grid is None or lookup_live.shape != grid.shape or lookup_live.dtype != np.float64 or not lookup_live.flags.c_contiguous:
-                raise ValueError("lookup_live must be a C-contiguous float64 array of the grid's shape")
-        a = PredictArgs(arr, len(arr), int(speculate), _p(limits), _p(cam), _p(inc), _p(grid), 0 if grid is None else len(grid),
-                        1 if use_table else 0, _p(crop), _p(lookup_live))
-        out, trace, n = np.empty(6), np.empty((len(arr), 6)), C.c_int64()
+        a, keep = self._predict_args(stages, limits, camera_pose, min_ang_inc, lookup_angles, lookup_crop, use_table, speculate, lookup_live)
+        out, trace, n = np.empty(6), np.empty((a.n_stages, 6)), C.c_int64()
         self._check(self._lib.rope_predict(self._ctx, C.byref(a), _p(out), _p(trace), C.byref(n)), 'rope_predict')
         return out, trace, int(n.value)
 

@@ -17,7 +17,7 @@ import numpy as np
 from ..config import Paths
 from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
 from ..crop import Crop
-from ..engine import (LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, StageDesc,
+from ..engine import (LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, STAGE_TSWEEP, StageDesc,
                       pack_target)
 from ..imgproc import dilate, erode, resize_linear
 from ..projection import Intrinsics
@@ -90,6 +90,8 @@ class Predictor:
 
     SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
+    BATCH = 64         # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
+                       # (rope_predict_batch); 1: frame after frame (rope_predict).  Same angles either way.
 
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
@@ -221,9 +223,15 @@ class Predictor:
             elif type(stage) is InterpolativeSweep and stage.divs >= 4:
                 d.kind, d.to_render, d.count = STAGE_ISWEEP, stage.to_render, stage.divs
                 d.range = nan if stage.range is None else float(stage.range)
+            elif type(stage) is TensorSweep and stage.divs >= 1:
+                d.kind, d.to_render, d.count = STAGE_TSWEEP, stage.to_render, stage.divs
+                d.range = nan if stage.range is None else float(stage.range)
             else:
                 return None
         return out
+
+    def _has_tsweep(self) -> bool:
+        return any(type(stage) is TensorSweep for stage in self.stages)
 
     # ------------------------------------------------------------------ target preparation
     def _downsample(self, base: np.ndarray, factor: int) -> np.ndarray:
@@ -310,14 +318,71 @@ class Predictor:
             return self._loadSynthetic(target_color, target_depth)
         return self._segmentLoad(target_color, target_depth)
 
-    def run_many(self, target_colors, target_depths, camera_poses=None, prefetch: bool = True) -> np.ndarray:
-        """run() over a sequence of frames -> (N, 6).  With prefetch, frame i+1 is prepared on a worker thread while
-        frame i's stages run on the GPU (numpy and the library both release the interpreter lock); the frames are
-        still predicted one after the other, in order, each from a fresh state — same angles as a loop of run()."""
+    def run_batch(self, prepared: list, camera_pose=None) -> np.ndarray:
+        """B prepared frames (Predictor.prepare) under ONE camera pose through the stage list in lockstep -> (B, 6): every step of a
+        stage is one device batch holding the rows of all frames, each row scored against its own frame's target
+        (rope_predict_batch).  The frames do not see each other — every state starts fresh (predict.py:144-148) — so the angles are
+        those of run() frame by frame; `self.traces[i]` is frame i's per-stage trace."""
+        if camera_pose is not None and np.any(np.asarray(camera_pose) != self.camera_pose):
+            self.changeCameraPose(camera_pose)
+        self._setStages()
+        native = self._native_stages() if (self.NATIVE and not self.preview and not self.reference_table_aliasing) else None
+        if native is None or len(prepared) == 0:
+            out = np.zeros((len(prepared), 6))
+            self.traces = []
+            for i, prep in enumerate(prepared):
+                out[i] = self.run(None, None, prepared=prep)
+                self.traces.append(self.trace)
+            return out
+        ts = np.stack([np.asarray(p.tgt_depth, np.float32) for p in prepared]) if self._has_tsweep() else None
+        self.engine.set_targets(np.stack([p.tq for p in prepared]), np.stack([p.lookup_f32 for p in prepared]),
+                                np.stack([p.flags for p in prepared]), ts)
+        angles, trace, n = self.engine.predict_batch(native, self.u_reader.joint_limits, self.camera_pose, self.min_ang_inc, self.lookup_angles,
+                                                     self.lookup_crop, self._lookup_table, self.SPECULATE)
+        self.evaluations += n
+        self.traces = [[(type(stage).__name__, trace[f, i].copy()) for i, stage in enumerate(self.stages)] for f in range(len(prepared))]
+        self.trace = self.traces[-1]
+        return angles
+
+    def _run_many_batched(self, target_colors, target_depths, camera_poses, batch: int) -> np.ndarray:
+        """run_many in groups of up to `batch` consecutive frames under one camera pose; the next group is prepared on worker
+        threads (host work only: down-sampling, masks, packing) while the current one is on the GPU."""
+        from concurrent.futures import ThreadPoolExecutor
+        from ..utils import cpu_budget
+        n = len(target_colors)
+        out = np.zeros((n, 6))
+        groups, lo = [], 0
+        while lo < n:                                   # consecutive frames with the same camera pose, at most `batch` of them
+            hi = lo + 1
+            while hi < n and hi - lo < batch and (camera_poses is None or np.array_equal(camera_poses[hi], camera_poses[lo])):
+                hi += 1
+            groups.append((lo, hi))
+            lo = hi
+        # the segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order
+        workers = max(1, min(8, cpu_budget() - 1)) if self.synthetic else 1
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            def submit(g):
+                return [pool.submit(self.prepare, target_colors[i], target_depths[i]) for i in range(*g)]
+            nxt = submit(groups[0])
+            for k, (lo, hi) in enumerate(groups):
+                preps = [f.result() for f in nxt]
+                if k + 1 < len(groups):
+                    nxt = submit(groups[k + 1])
+                out[lo:hi] = self.run_batch(preps, None if camera_poses is None else camera_poses[lo])
+        return out
+
+    def run_many(self, target_colors, target_depths, camera_poses=None, prefetch: bool = True, batch: int = None) -> np.ndarray:
+        """run() over a sequence of frames -> (N, 6).  By default BATCH frames at a time walk the stage list in lockstep
+        (run_batch).  With batch = 1: frame after frame, and with prefetch frame i+1 is prepared on a worker thread while
+        frame i's stages run on the GPU (numpy and the library both release the interpreter lock).  Every frame starts from a
+        fresh state either way — same angles as a loop of run()."""
         n = len(target_colors)
         out = np.zeros((n, 6))
         if n == 0:
             return out
+        batch = self.BATCH if batch is None else int(batch)
+        if batch > 1 and n > 1 and self.NATIVE and not self.preview and not self.reference_table_aliasing:
+            return self._run_many_batched(target_colors, target_depths, camera_poses, batch)
         pose = (lambda i: None) if camera_poses is None else (lambda i: camera_poses[i])
         if not prefetch or self.preview or n == 1:
             for i in range(n):
@@ -381,6 +446,8 @@ class Predictor:
         self.trace = []
         native = self._native_stages() if (self.NATIVE and not self.preview) else None
         if native is not None:
+            if self._has_tsweep():          # TensorSweep compares against the whole target depth, not the lookup plane (predict.py:363)
+                self.engine.set_target_tsweep(np.ascontiguousarray(self._tgt_depth, dtype=np.float32))
             angles, trace, n = self.engine.predict(native, limits, self.camera_pose, self.min_ang_inc, self.lookup_angles,
                                                    self.lookup_crop, self._lookup_table, self.SPECULATE, self._lookup_live)
             self.evaluations += n

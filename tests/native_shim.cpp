@@ -29,6 +29,22 @@ int rope_lookup_score(rope_ctx *, double *, int32_t *, double *)
     return ROPE_E_ARG;
 }
 
+// rope_predict_batch's rows carry the frame they belong to: the test's second callback scores each against that frame's target
+typedef int (*shim_targets_cb)(const double *cand, const int32_t *frame_of, int R, int n_render, int loss, const int32_t *crop, double *err_out);
+static shim_targets_cb g_tcb = nullptr;
+void shim_set_targets_callback(shim_targets_cb cb) { g_tcb = cb; }
+
+int rope_eval_targets(rope_ctx *, const double *cand, const int32_t *frame_of, int R, int n_render, int loss, const int32_t *crop, double *err_out)
+{
+    return g_tcb ? g_tcb(cand, frame_of, R, n_render, loss, crop, err_out) : ROPE_E_ARG;
+}
+
+int rope_lookup_score_targets(rope_ctx *, int32_t *, double *, double *)
+{
+    g_err = "shim: no stored table";
+    return ROPE_E_ARG;
+}
+
 // rope_set_robot_mesh (rope_meshlets.cpp) ends in rope_set_robot: here every array it hands over is read once, end to end
 // (so that a sanitised build sees any range it should not have), and the totals are kept for the test to look at.
 static int64_t g_robot[4];       // meshlets, vertices, triangles, checksum

@@ -107,6 +107,105 @@ def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculat
     assert calls[0] == len(grid) and max(calls[1:]) <= 26          # the lookup grid, then batches of at most 1 + 25 poses
 
 
+def test_frames_in_lockstep_equal_frame_by_frame(shim):
+    """rope_predict_batch (B frames through the stage list in lockstep, every step one batch over all frames) against the
+    sequential restatement per frame, and against rope_predict per frame: same angles after every stage.  Includes a custom list
+    with a TensorSweep stage (ROPE_STAGE_TSWEEP) and a frame without depth (all errors NaN) among the others."""
+    rb = helpers.robot()
+    lim = rb.joint_limits
+    pose = TILTED
+    intr, PV = helpers.camera('640_480_color', ds=8, pose=pose, as_predictor=True)
+    o = helpers.make_oracle(rb, intr, PV)
+    grid = helpers.slu_grid(lim, 3)
+    cover = o.coverage(crop_pose_grid(lim, intr.size, 6)[0], 6, threads=THREADS) != 0
+    r, c = np.where(cover)
+    crop = np.array([max(r.min() - 10, 0), min(r.max() + 10, intr.height - 1), max(c.min() - 10, 0), min(c.max() + 10, intr.width - 1)], np.int32)
+    names = rb.link_names
+    blue_of = {n: int(LINK_BLUE[i]) for i, n in enumerate(names)}
+    rng = np.random.default_rng(77)
+    targets = []
+    for f in range(4):
+        q_true = rng.uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+        depth, ids = o.render(q_true, 6)
+        if f == 2:                                           # a frame with nothing in it: NaN errors all the way
+            depth, ids = np.zeros_like(depth), np.full(ids.shape, 255, np.uint8)
+        tq, t32, flags, tgt, _, _ = helpers.synthetic_target(depth, ids)
+        blue = np.where(ids == 255, 0, np.asarray(LINK_BLUE)[np.minimum(ids, 5)]).astype(np.uint8)
+        targets.append(dict(tq=tq, t32=t32, flags=flags, tgt=tgt, blue=blue, full=np.ascontiguousarray(tgt, np.float32)))
+
+    def score(rows, fr, n_render, loss, crop_p):
+        if loss == orc.LOSS_LOOKUP:
+            return o.eval(rows, loss, n_render, fr['tq'], fr['t32'], np.ctypeslib.as_array(crop_p, (4,)), fr['flags'], threads=THREADS)
+        if loss == orc.LOSS_TSWEEP:
+            return o.eval(rows, loss, n_render, fr['tq'], fr['full'], None, fr['flags'], threads=THREADS)
+        return o.eval(rows, loss, n_render, fr['tq'], link_flags=fr['flags'], threads=THREADS)
+
+    batches = []
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double))
+    def answer_targets(cand, frame_of, n, n_render, loss, crop_p, err_out):
+        rows = np.ctypeslib.as_array(cand, (n, 6)).copy()
+        fo = np.ctypeslib.as_array(frame_of, (n,)).copy()
+        batches.append((n, len(set(fo.tolist()))))
+        out = np.ctypeslib.as_array(err_out, (n,))
+        for f in sorted(set(fo.tolist())):
+            with np.errstate(all='ignore'):
+                out[fo == f] = score(rows[fo == f], targets[f], n_render, loss, crop_p)
+        return 0
+
+    current = [0]
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32))
+    def answer_single(cand, n, n_render, loss, crop_p, err_out, best_idx):
+        rows = np.ctypeslib.as_array(cand, (n, 6)).copy()
+        with np.errstate(all='ignore'):
+            err = score(rows, targets[current[0]], n_render, loss, crop_p)
+        if err_out:
+            np.ctypeslib.as_array(err_out, (n,))[:] = err
+        if best_idx:
+            ok = ~np.isnan(err)
+            best_idx[0] = int(np.flatnonzero(ok)[np.argmin(err[ok])]) if ok.any() else 0
+        return 0
+    shim.shim_set_targets_callback.argtypes = [C.c_void_p]
+    shim.shim_set_targets_callback(C.cast(answer_targets, C.c_void_p))
+    shim.shim_set_callback(answer_single)
+    shim.rope_predict_batch.argtypes = [C.c_void_p, C.POINTER(PredictArgs), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    limits, cam, inc = np.ascontiguousarray(lim, np.float64), np.asarray(pose, np.float64), np.array([.005] * 6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tsweep = StageDesc(4, 6, 7, 1 << 2)                      # ROPE_STAGE_TSWEEP over U, 7 divisions, whole range
+    tsweep.range = NAN
+    tsweep.init_rate[:] = [NAN] * 6
+    for label, stages in (('SLU', _stages('SLU')), ('SL', _stages('SL')), ('custom', _stages('SL')[:2] + [tsweep] + _stages('SLU')[2:4])):
+        arr = (StageDesc * len(stages))(*stages)
+        B = len(targets)
+        for speculate in (3, 1):
+            args = PredictArgs(arr, len(arr), speculate, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop))
+            out, trace, n = np.empty((B, 6)), np.empty((B, len(arr), 6)), C.c_int64()
+            batches.clear()
+            assert shim.rope_predict_batch(C.c_void_p(1), C.byref(args), B, p(out), p(trace), C.byref(n)) == 0, shim.shim_last_error()
+            assert any(frames == B for _, frames in batches)              # steps really carry the rows of all frames
+            total = 0
+            for f in range(B):
+                current[0] = f
+                one, one_trace, n1 = np.empty(6), np.empty((len(arr), 6)), C.c_int64()
+                assert shim.rope_predict(C.c_void_p(1), C.byref(args), p(one), p(one_trace), C.byref(n1)) == 0, shim.shim_last_error()
+                assert np.array_equal(one_trace.view(np.uint64), trace[f].view(np.uint64)), (label, speculate, f)
+                assert np.array_equal(one.view(np.uint64), out[f].view(np.uint64))
+                total += n1.value
+                if label != 'custom' and speculate == 3:
+                    with np.errstate(all='ignore'):
+                        want, ref_trace, _ = predictor_ref.predict_reference(o, targets[f]['tgt'], targets[f]['blue'], names, blue_of, lim, pose,
+                                                                             grid, crop, label)
+                    for k, (kind, ang) in enumerate(ref_trace):
+                        assert np.array_equal(trace[f, k], ang, equal_nan=True), (label, f, k, kind)
+            assert n.value == total
+    # the table aliasing makes frames depend on their order: refused for a batch
+    live = grid.copy()
+    args = PredictArgs(arr, len(arr), 3, p(limits), p(cam), p(inc), p(grid), len(grid), 0, p(crop), p(live))
+    assert shim.rope_predict_batch(C.c_void_p(1), C.byref(args), B, p(out), p(trace), None) == -1
+    assert b'order' in shim.shim_last_error()
+
+
 def test_argument_checks_without_an_engine(shim):
     lim = np.ascontiguousarray(helpers.robot().joint_limits, np.float64)
     cam, inc = np.asarray(DEFAULT_CAMERA_POSE, np.float64), np.array([.005] * 6)
