@@ -103,6 +103,18 @@ int rope_pack_target(const double *depth, const uint8_t *mask_bits, int64_t n, u
  * dst is dense (H/f x W/f x channels). */
 int rope_downsample_even(const void *src, int H, int W, int channels, int64_t row_stride, int f, int kind, void *dst);
 
+/* Host only (no context): one frame of the synthetic path, camera arrays in, target planes out, in one pass: the down-sampling
+ * of Predictor._downsample (predict.py:378-381, as rope_downsample_even), the link masks read off channel 0 of the colour render
+ * and the lookup depth of _loadSynthetic (predict.py:445-469), the per-link flags and the packing of _load_target (predict.py:397-413).
+ *   color  H0 x W0 x 3 uint8 (BGR, only channel 0 is read), rows color_stride bytes apart
+ *   depth  H0 x W0 float32 (depth_kind 1) or float64 (2) metres, rows depth_stride bytes apart
+ *   f      down-sampling factor: 1 or even;  link_blue: n_links channel-0 values (DEFAULT_RENDER_COLORS, constants.py:65-91), the first
+ *          n_lookup_links of them the links of the lookup depth
+ *   out    tq, lookup_f32 (H0/f x W0/f), flags (8 bytes) as rope_set_target takes them; tgt_depth float64 or NULL */
+int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride, const void *depth, int depth_kind, int64_t depth_stride, int H0, int W0,
+                           int f, const int32_t *link_blue, int n_links, int n_lookup_links, uint64_t *tq, float *lookup_f32, double *tgt_depth,
+                           uint8_t *flags);
+
 /* Candidate joint vectors (C x 6 doubles) into HBM; they stay resident until replaced. */
 int rope_candidates_upload(rope_ctx *ctx, const double *cand, int C);
 

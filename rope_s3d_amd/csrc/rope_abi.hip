@@ -527,6 +527,72 @@ extern "C" int rope_downsample_even(const void *src, int H, int W, int channels,
     return ROPE_OK;
 }
 
+// Host only: one frame of the synthetic path from the camera's arrays to what rope_set_target(s) takes, in one pass — the
+// down-sampling of Predictor._downsample (predict.py:378-381: cv2.resize INTER_LINEAR; the taps and roundings of
+// rope_downsample_even), the link masks read off channel 0 of the colour render and the lookup depth of _loadSynthetic
+// (predict.py:445-469), the per-link flags and the packing of _load_target (predict.py:397-413, rope_pack_target).
+extern "C" int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride, const void *depth, int depth_kind, int64_t depth_stride,
+                                      int H0, int W0, int f, const int32_t *link_blue, int n_links, int n_lookup_links,
+                                      uint64_t *tq, float *lookup_f32, double *tgt_depth, uint8_t *flags)
+{
+    if (!color || !depth || !link_blue || !tq || !lookup_f32 || !flags) return ROPE_E_ARG;
+    if (H0 < 1 || W0 < 1 || f < 1 || (f > 1 && (f & 1)) || H0 % f || W0 % f || (depth_kind != 1 && depth_kind != 2)) return ROPE_E_ARG;
+    if (n_links < 1 || n_links > ROPE_MAX_LINKS || n_lookup_links < 0 || n_lookup_links > n_links) return ROPE_E_ARG;
+    const int H = H0 / f, W = W0 / f, a = f / 2 - 1, b = f / 2;
+    const double Q32 = 4294967296.0, top = 549755813887.0;          // 2^32, 2^39 - 1
+    int64_t n_mask[ROPE_MAX_LINKS] = {}, n_depth[ROPE_MAX_LINKS] = {};
+    for (int y = 0; y < H; y++) {
+        const int ya = f > 1 ? y * f + a : y, yb = f > 1 ? y * f + b : y;
+        const uint8_t *c0 = color + (int64_t)ya * color_stride, *c1 = color + (int64_t)yb * color_stride;
+        const char *d0 = (const char *)depth + (int64_t)ya * depth_stride, *d1 = (const char *)depth + (int64_t)yb * depth_stride;
+        for (int x = 0; x < W; x++) {
+            const size_t xa = f > 1 ? (size_t)(x * f + a) : (size_t)x, xb = f > 1 ? (size_t)(x * f + b) : (size_t)x;
+            int blue;
+            double d;
+            if (f > 1) {
+                // OpenCV's fixed-point path for uint8 (rope_downsample_even, kind 0); channel 0 of three interleaved
+                const int64_t t = ((int64_t)c0[3 * xa] * 1024 + (int64_t)c0[3 * xb] * 1024) >> 4, u = ((int64_t)c1[3 * xa] * 1024 + (int64_t)c1[3 * xb] * 1024) >> 4;
+                const int64_t v = (((1024 * t) >> 16) + ((1024 * u) >> 16) + 2) >> 2;
+                blue = (int)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                if (depth_kind == 1) {
+                    const float *p0 = (const float *)d0, *p1 = (const float *)d1;
+                    const float tp = p0[xa] * 0.5f + p0[xb] * 0.5f, bt = p1[xa] * 0.5f + p1[xb] * 0.5f;
+                    d = (double)(tp * 0.5f + bt * 0.5f);
+                } else {
+                    const double *p0 = (const double *)d0, *p1 = (const double *)d1;
+                    const double tp = p0[xa] * 0.5 + p0[xb] * 0.5, bt = p1[xa] * 0.5 + p1[xb] * 0.5;
+                    d = tp * 0.5 + bt * 0.5;
+                }
+            } else {
+                blue = c0[3 * xa];
+                d = depth_kind == 1 ? (double)((const float *)d0)[xa] : ((const double *)d0)[xa];
+            }
+            unsigned bits = 0;
+            bool hit = false;
+            for (int l = 0; l < n_links; l++)
+                if (blue == link_blue[l]) {
+                    bits |= 1u << l;
+                    n_mask[l]++;
+                    if (d != 0.0) n_depth[l]++;                    // NaN counts, as `depth != 0` does
+                    if (l < n_lookup_links) hit = true;
+                }
+            const size_t o = (size_t)y * W + x;
+            if (tgt_depth) tgt_depth[o] = d;
+            lookup_f32[o] = (float)(d * (hit ? 1.0 : 0.0));        // target_depth * hit (predict.py:449-454): NaN stays NaN
+            double q = (std::isfinite(d) && d > 0.0) ? std::nearbyint(d * Q32) : 0.0;
+            q = q < top ? q : top;
+            tq[o] = (uint64_t)q | ((uint64_t)bits << 40);
+        }
+    }
+    std::memset(flags, 0, 8);
+    for (int l = 0; l < n_links; l++)
+        if (n_mask[l] > 0) {                                       // np.sum(mask) > 0 (predict.py:465)
+            flags[l] |= 1;
+            if ((double)n_depth[l] > 0.05 * (double)n_mask[l]) flags[l] |= 2;      // predict.py:495, a fact of the target alone
+        }
+    return ROPE_OK;
+}
+
 // Can a vertex of the robot get behind the near plane of camera PV (P·V, row-major doubles)?  z + w is affine in the world
 // position; over the ball of radius `reach` about the base origin it is at least its value at the origin minus |gradient|
 // times the radius.  Conservative with a centimetre to spare: "no" means the kernels without the clipping code draw every

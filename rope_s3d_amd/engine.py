@@ -23,7 +23,8 @@ ABI_SYMBOLS = (
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_set_strategy',
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
     'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
-    'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch')
+    'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
+    'rope_prepare_synthetic')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP, STAGE_TSWEEP = 0, 1, 2, 3, 4
@@ -105,6 +106,7 @@ def load_library(path: str = None):
     lib.rope_eval_targets.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.rope_lookup_score_targets.argtypes = [vp, vp, vp, vp]
     lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
+    lib.rope_prepare_synthetic.argtypes = [vp, C.c_int64, vp, i32, C.c_int64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -131,6 +133,27 @@ def pack_target(depth: np.ndarray, mask_bits: np.ndarray = None) -> np.ndarray:
     if mask_bits is not None:
         q |= np.asarray(mask_bits, np.uint64) << np.uint64(40)
     return np.ascontiguousarray(q)
+
+
+def prepare_synthetic(color: np.ndarray, depth: np.ndarray, f: int, link_blue, n_lookup_links: int, tq: np.ndarray, lookup_f32: np.ndarray,
+                      flags: np.ndarray, tgt_depth: np.ndarray = None) -> bool:
+    """rope_prepare_synthetic: one frame of the synthetic path into the given output arrays (host code, interpreter lock released).
+    False when the arrays' layout is not one the library takes (the caller then goes the numpy way)."""
+    if color.dtype != np.uint8 or color.ndim != 3 or color.shape[2] != 3 or color.strides[2] != 1 or color.strides[1] != 3 or color.strides[0] < 0:
+        return False
+    kind = {np.dtype(np.float32): 1, np.dtype(np.float64): 2}.get(depth.dtype)
+    if kind is None or depth.ndim != 2 or depth.shape != color.shape[:2] or depth.strides[1] != depth.itemsize or depth.strides[0] < 0:
+        return False
+    H0, W0 = depth.shape
+    if f < 1 or (f > 1 and f % 2) or H0 % f or W0 % f:
+        return False
+    for a, dt in ((tq, np.uint64), (lookup_f32, np.float32), (flags, np.uint8)) + (((tgt_depth, np.float64),) if tgt_depth is not None else ()):
+        assert a.dtype == dt and a.flags.c_contiguous
+    assert tq.shape == (H0 // f, W0 // f) == lookup_f32.shape and flags.size >= 8
+    lb = np.ascontiguousarray(link_blue, np.int32)
+    rc = load_library().rope_prepare_synthetic(C.c_void_p(color.ctypes.data), color.strides[0], C.c_void_p(depth.ctypes.data), kind, depth.strides[0],
+                                               H0, W0, int(f), _p(lb), len(lb), int(n_lookup_links), _p(tq), _p(lookup_f32), _p(tgt_depth), _p(flags))
+    return rc == 0
 
 
 class Engine:

@@ -18,7 +18,7 @@ from ..config import Paths
 from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
 from ..crop import Crop
 from ..engine import (LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, STAGE_TSWEEP, StageDesc,
-                      pack_target)
+                      pack_target, prepare_synthetic)
 from ..imgproc import dilate, erode, resize_linear
 from ..projection import Intrinsics
 from ..simulation.lookup import RobotLookupManager
@@ -90,6 +90,7 @@ class Predictor:
 
     SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
+    NATIVE_PREPARE = True   # synthetic path: prepare() as one pass in the library (rope_prepare_synthetic); False: the numpy steps, same arrays
     BATCH = 64         # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
                        # (rope_predict_batch); 1: frame after frame (rope_predict).  Same angles either way.
 
@@ -307,10 +308,36 @@ class Predictor:
                 masks[link] = m
         return self._pack_target(target_depth, lookup_depth, masks, target_color)       # target_color: `output` of predict.py:469
 
+    def _prepare_synthetic_native(self, target_color, target_depth, tq=None, lookup_f32=None, flags=None, tgt_depth=None):
+        """The synthetic path's prepare() as ONE pass in the library (rope_prepare_synthetic: the same taps, comparisons, counts and
+        roundings as _downsample + _loadSynthetic + _pack_target), into the given arrays (slots of a batch) or fresh ones.  None when
+        the frame's layout or the colour dictionary is not what that pass takes — the numpy steps do it then."""
+        if not self.synthetic or self.preview or any(k not in self.color_dict for k in self.link_names):
+            return None
+        color, depth = np.asarray(target_color), np.asarray(target_depth)
+        if color.ndim != 3 or depth.ndim != 2 or depth.dtype not in (np.float32, np.float64):
+            return None
+        f = int(self.ds_factor)
+        if f < 1 or (f > 1 and f % 2) or depth.shape[0] % f or depth.shape[1] % f:
+            return None
+        shape = (depth.shape[0] // f, depth.shape[1] // f)
+        tq = np.empty(shape, np.uint64) if tq is None else tq
+        lookup_f32 = np.empty(shape, np.float32) if lookup_f32 is None else lookup_f32
+        flags = np.zeros(8, np.uint8) if flags is None else flags
+        tgt_depth = np.empty(shape, np.float64) if tgt_depth is None else tgt_depth
+        blue = [int(self.color_dict[k][0]) for k in self.link_names]
+        if not prepare_synthetic(color, depth, f, blue, LOOKUP_NUM_RENDERED, tq, lookup_f32, flags, tgt_depth):
+            return None
+        return PreparedTarget(tgt_depth, lookup_f32, None, tq, flags, None)
+
     def prepare(self, target_color, target_depth) -> PreparedTarget:
         """The host half of run(): down-sampling, link masks (colour read-off or the segmenter), body masking and
         packing (predict.py:132-137).  Touches neither the engine nor the Predictor's state, so the next frame can
         be prepared while this one is on the GPU (run_many)."""
+        if self.NATIVE_PREPARE:
+            prep = self._prepare_synthetic_native(target_color, target_depth)
+            if prep is not None:
+                return prep
         target_depth = self._downsample(np.asarray(target_depth), self.ds_factor)
         if target_depth.dtype != np.float64:
             target_depth = target_depth.astype(np.float64)
@@ -326,8 +353,7 @@ class Predictor:
         if camera_pose is not None and np.any(np.asarray(camera_pose) != self.camera_pose):
             self.changeCameraPose(camera_pose)
         self._setStages()
-        native = self._native_stages() if (self.NATIVE and not self.preview and not self.reference_table_aliasing) else None
-        if native is None or len(prepared) == 0:
+        if not self._batch_ok() or len(prepared) == 0:
             out = np.zeros((len(prepared), 6))
             self.traces = []
             for i, prep in enumerate(prepared):
@@ -335,18 +361,28 @@ class Predictor:
                 self.traces.append(self.trace)
             return out
         ts = np.stack([np.asarray(p.tgt_depth, np.float32) for p in prepared]) if self._has_tsweep() else None
-        self.engine.set_targets(np.stack([p.tq for p in prepared]), np.stack([p.lookup_f32 for p in prepared]),
+        return self._run_planes(np.stack([p.tq for p in prepared]), np.stack([p.lookup_f32 for p in prepared]),
                                 np.stack([p.flags for p in prepared]), ts)
-        angles, trace, n = self.engine.predict_batch(native, self.u_reader.joint_limits, self.camera_pose, self.min_ang_inc, self.lookup_angles,
-                                                     self.lookup_crop, self._lookup_table, self.SPECULATE)
-        self.evaluations += n
-        self.traces = [[(type(stage).__name__, trace[f, i].copy()) for i, stage in enumerate(self.stages)] for f in range(len(prepared))]
+
+    def _batch_ok(self) -> bool:
+        """The current stage list can walk many frames in lockstep (rope_predict_batch)."""
+        return self.NATIVE and not self.preview and not self.reference_table_aliasing and self._native_stages() is not None
+
+    def _run_planes(self, tq, lookup_f32, flags, tsweep=None) -> np.ndarray:
+        """run_batch on the frames' stacked target planes: (B,H,W) uint64, (B,H,W) float32, (B,8) uint8 [, (B,H,W) float32]."""
+        n = len(tq)
+        self.engine.set_targets(tq, lookup_f32, flags, tsweep)
+        angles, trace, n_eval = self.engine.predict_batch(self._native_stages(), self.u_reader.joint_limits, self.camera_pose, self.min_ang_inc,
+                                                          self.lookup_angles, self.lookup_crop, self._lookup_table, self.SPECULATE)
+        self.evaluations += n_eval
+        self.traces = [[(type(stage).__name__, trace[f, i].copy()) for i, stage in enumerate(self.stages)] for f in range(n)]
         self.trace = self.traces[-1]
         return angles
 
     def _run_many_batched(self, target_colors, target_depths, camera_poses, batch: int) -> np.ndarray:
-        """run_many in groups of up to `batch` consecutive frames under one camera pose; the next group is prepared on worker
-        threads (host work only: down-sampling, masks, packing) while the current one is on the GPU."""
+        """run_many in groups of up to `batch` consecutive frames under one camera pose.  Worker threads prepare a group's frames
+        straight into the slots of its stacked planes (host work only: down-sampling, masks, packing — the library's one-pass form
+        where it applies) while the group before it is on the GPU."""
         from concurrent.futures import ThreadPoolExecutor
         from ..utils import cpu_budget
         n = len(target_colors)
@@ -358,17 +394,37 @@ class Predictor:
                 hi += 1
             groups.append((lo, hi))
             lo = hi
+        self._setStages()
+        want_ts = self._has_tsweep()
+        H, W = self.intrinsics.height, self.intrinsics.width
+
+        def fill(planes, k, i):
+            tq, t32, fl, ts = planes
+            prep = self._prepare_synthetic_native(target_colors[i], target_depths[i], tq[k], t32[k], fl[k]) if self.NATIVE_PREPARE else None
+            if prep is None:
+                prep = self.prepare(target_colors[i], target_depths[i])
+                tq[k], t32[k], fl[k] = prep.tq, prep.lookup_f32, prep.flags
+            if ts is not None:
+                ts[k] = prep.tgt_depth
+
         # the segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order
         workers = max(1, min(8, cpu_budget() - 1)) if self.synthetic else 1
         with ThreadPoolExecutor(max_workers=workers) as pool:
             def submit(g):
-                return [pool.submit(self.prepare, target_colors[i], target_depths[i]) for i in range(*g)]
+                b = g[1] - g[0]
+                planes = (np.empty((b, H, W), np.uint64), np.empty((b, H, W), np.float32), np.zeros((b, 8), np.uint8),
+                          np.empty((b, H, W), np.float32) if want_ts else None)
+                return planes, [pool.submit(fill, planes, k, g[0] + k) for k in range(b)]
             nxt = submit(groups[0])
             for k, (lo, hi) in enumerate(groups):
-                preps = [f.result() for f in nxt]
+                planes, jobs = nxt
+                for j in jobs:
+                    j.result()
                 if k + 1 < len(groups):
                     nxt = submit(groups[k + 1])
-                out[lo:hi] = self.run_batch(preps, None if camera_poses is None else camera_poses[lo])
+                if camera_poses is not None and np.any(np.asarray(camera_poses[lo]) != self.camera_pose):
+                    self.changeCameraPose(camera_poses[lo])
+                out[lo:hi] = self._run_planes(*planes)
         return out
 
     def run_many(self, target_colors, target_depths, camera_poses=None, prefetch: bool = True, batch: int = None) -> np.ndarray:
@@ -381,7 +437,8 @@ class Predictor:
         if n == 0:
             return out
         batch = self.BATCH if batch is None else int(batch)
-        if batch > 1 and n > 1 and self.NATIVE and not self.preview and not self.reference_table_aliasing:
+        self._setStages()
+        if batch > 1 and n > 1 and self._batch_ok():
             return self._run_many_batched(target_colors, target_depths, camera_poses, batch)
         pose = (lambda i: None) if camera_poses is None else (lambda i: camera_poses[i])
         if not prefetch or self.preview or n == 1:

@@ -560,3 +560,47 @@ def test_real_mode_shades_a_depth_image():
     assert (img[10:30, 10:30, 0] == 200).all()                            # its border: differences stay inside the link
     tilted = img[37:53, 12:38, 0]
     assert 20 < tilted.mean() < 190 and tilted.std() < 30 and (tilted[0] == tilted[-1]).all()       # darker, and the same along a row of equal depth
+
+
+def test_native_synthetic_preparation_equals_the_numpy_steps():
+    """rope_prepare_synthetic (down-sampling + link masks off the colour render + lookup depth + flags + packing in one pass in the
+    library) against Predictor's numpy steps (_downsample, _loadSynthetic, _pack_target): every output array bit for bit —
+    factors 1, 2 and 8, float32 and float64 depth, zeros, NaN and negative depths, colours that belong to no link, a link that
+    is not in the frame, a link whose mask has too little depth (the 5 % flag)."""
+    import types
+    from rope_s3d_amd import imgproc
+    from rope_s3d_amd.engine import prepare_synthetic
+    from rope_s3d_amd.prediction.predict import Predictor
+    names = ['base_link', 'link_1_s', 'link_2_l', 'link_3_u', 'link_4_r', 'link_5_b']
+    cols = constants.DEFAULT_RENDER_COLORS
+    color_dict = {n: cols[i] for i, n in enumerate(names + ['link_6_t'])}
+    rng = np.random.default_rng(12)
+    for (H0, W0), f, dt in (((96, 128), 1, np.float32), ((96, 128), 2, np.float64), ((144, 256), 8, np.float32), ((90, 160), 1, np.float64)):
+        blue = np.array([c[0] for c in cols[:6]] + [99, 255], np.uint8)
+        labels = rng.integers(0, 8, (H0 // 16 + 1, W0 // 16 + 1))
+        labels = np.kron(labels, np.ones((16, 16), int))[:H0, :W0]                     # blobs of one colour: masks survive the down-sampling
+        labels[labels == 3] = 0                                                        # link_3_u never shows
+        color = np.zeros((H0, W0, 3), np.uint8)
+        color[..., 0] = blue[labels]
+        color[..., 1:] = rng.integers(0, 255, (H0, W0, 2))
+        depth = (rng.uniform(0.5, 3.0, (H0, W0)) * (rng.uniform(size=(H0, W0)) > .2)).astype(dt)
+        depth[labels == 4] *= (rng.uniform(size=(H0, W0)) > .995)[labels == 4]         # link_4_r: under 5 % of its mask has depth (also after four-tap averaging)
+        depth[5, 7], depth[9, 11], depth[13, 3] = np.nan, -1.0, np.inf
+        fake = types.SimpleNamespace(ds_factor=f, color_dict=color_dict, link_names=names, u_reader=types.SimpleNamespace(mesh_names=names + ['link_6_t']),
+                                     _downsample=lambda base, factor: imgproc.resize_linear(base, base.shape[1] // factor, base.shape[0] // factor))
+        fake._pack_target = lambda *a, **k: Predictor._pack_target(fake, *a, **k)
+        d_small = fake._downsample(depth, f)
+        with np.errstate(invalid='ignore'):
+            want = Predictor._loadSynthetic(fake, color, d_small.astype(np.float64))
+        H, W = H0 // f, W0 // f
+        tq, t32, flags, tgt = np.empty((H, W), np.uint64), np.empty((H, W), np.float32), np.zeros(8, np.uint8), np.empty((H, W), np.float64)
+        assert prepare_synthetic(color, depth, f, [color_dict[n][0] for n in names], 6, tq, t32, flags, tgt)
+        assert np.array_equal(tq, want.tq) and np.array_equal(flags, want.flags)
+        assert np.array_equal(t32.view(np.uint32), want.lookup_f32.view(np.uint32))
+        assert np.array_equal(tgt.view(np.uint64), want.tgt_depth.view(np.uint64))
+        assert flags[3] == 0 and flags[4] == 1 and flags[1] == 3
+        # a strided view (every other row of a taller frame) is taken as it is; a reversed one is refused
+        tall_c, tall_d = np.repeat(color, 2, axis=0), np.repeat(depth, 2, axis=0)
+        tq2 = np.empty_like(tq)
+        assert prepare_synthetic(tall_c[::2], tall_d[::2], f, [color_dict[n][0] for n in names], 6, tq2, t32, flags, None) and np.array_equal(tq2, tq)
+        assert not prepare_synthetic(color[:, ::-1], depth, f, [color_dict[n][0] for n in names], 6, tq2, t32, flags, None)
