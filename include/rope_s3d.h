@@ -115,6 +115,12 @@ int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride, const voi
                            int f, const int32_t *link_blue, int n_links, int n_lookup_links, uint64_t *tq, float *lookup_f32, double *tgt_depth,
                            uint8_t *flags);
 
+/* Page-locked host memory for the planes handed to rope_set_target / rope_set_targets / rope_set_frames: copies out of it go to the
+ * device in one transfer at the link's rate, instead of chunk by chunk through the library's own staging block (what pageable
+ * memory needs).  Optional — any host pointer is accepted everywhere.  NULL when the allocation fails. */
+void *rope_host_alloc(size_t bytes);
+void rope_host_free(void *p);
+
 /* Candidate joint vectors (C x 6 doubles) into HBM; they stay resident until replaced. */
 int rope_candidates_upload(rope_ctx *ctx, const double *cand, int C);
 

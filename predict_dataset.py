@@ -60,10 +60,10 @@ def run(args):
         kwargs['lookup_divisions'] = int(args.lookup_divisions)
     am = Predictor(ds_factor=args.ds_factor, camera_pose=ds.camera_pose[0], preview=False, base_intrin=ds.intrinsics,
                    do_angles=args.angs, model_ds=args.dataset, device=gpu, **kwargs)
-    # Frames are independent, and one frame's ~25 short dependent batches leave the GPU idle between them: k Predictors
-    # (own context and stream each) fed by k threads fill those gaps (prediction/pool.py).  Not with a segmenter that keeps
-    # per-chunk state or a network on the GPU: with the network's thread beside them, 2 / 4 / 8 Predictors sharing one
-    # batch-ahead segmenter were slower than one (195-232 against 249 frames/s, tools/bench_pipeline.py).
+    # Frames are independent (predict_dataset.py:43-44 is a plain loop; fresh state per frame, predict.py:144-148): ONE Predictor
+    # takes a chunk's frames through the stage list in lockstep (Predictor.run_many -> rope_predict_batch: every step one device
+    # batch over all frames' rows), the next frames prepared on worker threads meanwhile.  -predictors k > 1 is the older way of
+    # filling the GPU — k Predictors (own context and stream each) fed by k threads (prediction/pool.py) — kept for comparison.
     n_pred = max(1, int(getattr(args, 'predictors', 1) or 1))
     pool = None
     if n_pred > 1 and am.synthetic:
@@ -75,20 +75,30 @@ def run(args):
 
     lo, hi = shard_range(ds.length, rank, world)
     out = np.zeros((hi - lo, 6))
-    chunk = 200                                                 # the reference reads ~200 frames at a time (predict_dataset.py:27-41)
-    for start in range(lo, hi, chunk):
+    chunk = max(200, 2 * (getattr(args, 'batch', None) or 0))   # the reference reads ~200 frames at a time (predict_dataset.py:27-41)
+
+    def read(start):
         end = min(start + chunk, hi)
         # slices, not copies (predict_dataset.py:39-41 copies): an HDF5 slice is already a fresh array, and a memory-mapped
         # one is read by the worker that needs it — with ds_factor 8 the down-sampling touches a third of its pages
-        og_imgs = ds.og_img[start:end]
-        dms = ds.depthmaps[start:end]
-        cam_poses = np.copy(ds.camera_pose[start:end])
+        return end, ds.og_img[start:end], ds.depthmaps[start:end], np.copy(ds.camera_pose[start:end])
+
+    from concurrent.futures import ThreadPoolExecutor
+    reader = ThreadPoolExecutor(max_workers=1)                  # the next chunk comes off the disk while this one is predicted
+    nxt = reader.submit(read, lo) if lo < hi else None
+    for start in range(lo, hi, chunk):
+        end, og_imgs, dms, cam_poses = nxt.result()
+        nxt = reader.submit(read, end) if end < hi else None
         seg = None if am.synthetic else getattr(am, 'seg', None)
         if hasattr(seg, 'announce'):                          # the chunk's frames through the network in batches of 8
             seg.announce([am._downsample(og_imgs[i], am.ds_factor) for i in range(end - start)])
         # frame by frame as predict_dataset.py:43-44, with the next frame's host preparation (down-sampling, masks,
         # segmentation) running beside the current frame's device work
-        out[start - lo:end - lo] = (pool or am).run_many(og_imgs, dms, cam_poses)
+        if pool is not None:
+            out[start - lo:end - lo] = pool.run_many(og_imgs, dms, cam_poses)
+        else:
+            out[start - lo:end - lo] = am.run_many(og_imgs, dms, cam_poses, batch=getattr(args, 'batch', None))
+    reader.shutdown()
     full = gather_rows(out, ds.length, device=device)
     if rank == 0:
         np.save(f'predictions_{os.path.basename(os.path.normpath(args.dataset))}.npy', full)
@@ -109,7 +119,10 @@ if __name__ == "__main__":
                         help="'maskrcnn': segment every frame with the Mask R-CNN stage instead of reading a synthetic set's colours; "
                              "'color': a colour-coded set through the segmentation path with exact masks.")
     parser.add_argument('-lookup_divisions', type=int, default=None, help="Lookup grid divisions per joint (default: the reference's size rule).")
-    parser.add_argument('-predictors', type=int, default=4,
-                        help="Predictors (engine contexts + threads) per GPU when the link masks come from the colour render; 1 = one frame at a time.")
+    parser.add_argument('-predictors', type=int, default=1,
+                        help="Predictors (engine contexts + threads) per GPU when the link masks come from the colour render; default 1: "
+                             "one Predictor walking -batch frames in lockstep.")
+    parser.add_argument('-batch', type=int, default=None,
+                        help="Frames that walk the stage list in lockstep (one device batch per step over all of them); default: by frame size, 16..256; 1: frame after frame.")
     parser.add_argument('-weights', type=str, default=None, help="weights for -segmenter maskrcnn: the reference's trained Keras .h5 or a torch state_dict (random weights otherwise).")
     run(parser.parse_args())

@@ -109,14 +109,15 @@ struct rope_ctx {
     // stored lookup table (cropped sqrt-depth of a pose grid)
     float *d_table = nullptr;                  // dense rows while a table is built (freed once it is packed)
     size_t table_cap = 0;
-    // the stored table: per row the rectangle that holds its samples, its values in d_tpack at d_toff (rope_lookup_build)
-    ushort4 *d_trect = nullptr;
+    // the stored table (rope_lookup_build): per row d_tcount groups of four samples from d_toff on — d_tgoff: where in the crop,
+    // d_tgval: the four values
+    uint32_t *d_tcount = nullptr, *d_tgoff = nullptr;
     unsigned long long *d_toff = nullptr, *d_tused = nullptr;
-    float *d_tpack = nullptr;
+    float4 *d_tgval = nullptr;
     uint64_t *d_ttotal = nullptr;
     size_t trow_cap = 0;
     int table_C = 0, table_crop[4] = {0, 0, 0, 0};
-    size_t table_floats = 0;                   // floats the packed table holds
+    size_t table_groups = 0;                   // groups the stored table holds
     uint64_t *d_zero_total = nullptr;
     // scores of the table's rows: buffers of their own (a grid may hold more rows than one candidate batch)
     uint64_t *d_tsums = nullptr;
@@ -249,9 +250,33 @@ extern "C" int rope_create(rope_ctx **out, int device)
     return ROPE_OK;
 }
 
+// page-locked host memory (rope_host_alloc, or anything else registered with the runtime)?
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // pageable memory: an error by design
+    return attr.type == hipMemoryTypeHost;
+}
+
+extern "C" void *rope_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+extern "C" void rope_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 static int copy_h2d_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
 {
     constexpr size_t CHUNK = 8u << 20;
+    if (bytes >= (64u << 10) && is_pinned_host(src)) {     // already page-locked: one copy at the link's rate, no staging; the caller synchronises
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return ROPE_OK;
+    }
     if (!c->h_copy) HIP_TRY(c, hipHostMalloc((void **)&c->h_copy, 2 * CHUNK, hipHostMallocDefault));   // two halves, alternating
     int half = 0;
     for (size_t off = 0; off < bytes; off += CHUNK, half ^= 1) {
@@ -282,7 +307,7 @@ extern "C" void rope_destroy(rope_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
-                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_trect, c->d_toff, c->d_tused, c->d_tpack, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_touched, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
+                    c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_tcount, c->d_toff, c->d_tused, c->d_tgoff, c->d_tgval, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_touched, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3], c->d_fts32, c->d_fflags, c->d_tg_total[0], c->d_tg_total[1], c->d_tg_total[2],
                     c->d_tg_total[3], c->d_tg_empty, c->d_frame_of, c->d_tg_t32c, c->d_tg_ltotal, c->d_tg_scores, c->d_tg_best, c->d_t32ts};
@@ -416,7 +441,7 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
         HIP_TRY(c, realloc_dev(&c->d_t32, n));
         HIP_TRY(c, realloc_dev(&c->d_t32ts, n));
         HIP_TRY(c, realloc_dev(&c->d_key, n));
-        HIP_TRY(c, realloc_dev(&c->d_depth, n));
+        HIP_TRY(c, realloc_dev(&c->d_depth, n + 4));         // + 4: the cropped target of rope_lookup_score is read up to three floats past its end
         HIP_TRY(c, realloc_dev(&c->d_ids, n));
         HIP_TRY(c, realloc_dev(&c->d_cover, n));
         for (int k = 0; k < 4; k++) {
@@ -1144,30 +1169,31 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
         HIP_TRY(c, launch_raster(MODE_TABLE, ROPE_LOSS_LOOKUP, c->C, c->stream, fp, c->rp, a, use_clip(c)));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    // keep of every row only the rectangle that holds its samples (the crop is the box of all poses together), then let the
-    // dense rows go: the table is read once per frame from end to end, and this is what that pass streams
+    // keep of every row only the groups of samples that hold something (the crop is the box of all poses together, and a pose
+    // fills a fraction of its own box), then let the dense rows go: this is what the per-frame pass reads
     if ((size_t)C > c->trow_cap) {
         c->trow_cap = 0;
-        HIP_TRY(c, realloc_dev(&c->d_trect, (size_t)C));
+        HIP_TRY(c, realloc_dev(&c->d_tcount, (size_t)C));
         HIP_TRY(c, realloc_dev(&c->d_toff, (size_t)C));
         c->trow_cap = (size_t)C;
     }
     if (!c->d_tused) HIP_TRY(c, realloc_dev(&c->d_tused, (size_t)1));
     if (!c->d_ttotal) HIP_TRY(c, realloc_dev(&c->d_ttotal, (size_t)ROPE_SUM_WORDS));
-    float *all = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&all, (need + 4 * (size_t)C) * sizeof(float)));
+    const int cw = crop[3] - crop[2] + 1, ch = crop[1] - crop[0] + 1;
     unsigned long long used = 0;
     hipError_t e = hipMemsetAsync(c->d_tused, 0, sizeof(unsigned long long), c->stream);
-    if (e == hipSuccess) e = launch_table_pack(c->stream, crop[3] - crop[2] + 1, crop[1] - crop[0] + 1, c->d_table, C, c->d_trect, c->d_toff, c->d_tused, all);
+    if (e == hipSuccess) e = launch_table_count(c->stream, cw, ch, c->d_table, C, c->d_tcount, c->d_toff, c->d_tused);
     if (e == hipSuccess) e = hipMemcpyAsync(&used, c->d_tused, sizeof(used), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (c->d_tpack) { (void)hipFree(c->d_tpack); c->d_tpack = nullptr; }
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tpack, std::max<size_t>(used, 4) * sizeof(float));
-    if (e == hipSuccess && used) e = hipMemcpy(c->d_tpack, all, used * sizeof(float), hipMemcpyDeviceToDevice);
-    (void)hipFree(all);
+    if (c->d_tgoff) { (void)hipFree(c->d_tgoff); c->d_tgoff = nullptr; }
+    if (c->d_tgval) { (void)hipFree(c->d_tgval); c->d_tgval = nullptr; }
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tgoff, std::max<size_t>(used, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tgval, std::max<size_t>(used, 1) * sizeof(float4));
+    if (e == hipSuccess) e = launch_table_fill(c->stream, cw, ch, c->d_table, C, c->d_toff, c->d_tgoff, c->d_tgval);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_table); c->d_table = nullptr; c->table_cap = 0;
     HIP_TRY(c, e);
-    c->table_floats = used;
+    c->table_groups = used;
     c->table_C = C;
     std::memcpy(c->table_crop, crop, 4 * sizeof(int32_t));
     return ROPE_OK;
@@ -1182,7 +1208,7 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
-    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_trect, c->d_toff, c->d_tpack, c->table_C, c->d_t32, c->d_depth /* scratch: H x W floats */,
+    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_tcount, c->d_toff, c->d_tgoff, c->d_tgval, c->table_C, c->d_t32, c->d_depth /* scratch: H x W + 4 floats */,
                                   c->d_ttotal, c->d_tsums));
     HIP_TRY(c, launch_finalize(c->stream, c->d_tsums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_terr));
     if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_terr, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1422,9 +1448,15 @@ extern "C" int rope_lookup_score_targets(rope_ctx *c, int32_t *best_idx, double 
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const size_t crop_px = (size_t)(fp.r1 - fp.r0 + 1) * (size_t)(fp.c1 - fp.c0 + 1), N = (size_t)c->n_targets;
-    if (N * crop_px > c->tg_t32c_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->tg_t32c_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_t32c, N * crop_px)); c->tg_t32c_cap = N * crop_px; }
+    if (N * crop_px > c->tg_t32c_cap) {           // + 4: a group at the crop's right edge reads up to three floats past the last frame's crop
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->tg_t32c_cap = 0;
+        HIP_TRY(c, realloc_dev(&c->d_tg_t32c, N * crop_px + 4));
+        HIP_TRY(c, hipMemset(c->d_tg_t32c, 0, (N * crop_px + 4) * sizeof(float)));
+        c->tg_t32c_cap = N * crop_px;
+    }
     if (N * c->table_C > c->tg_scores_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->tg_scores_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_scores, N * c->table_C)); c->tg_scores_cap = N * c->table_C; }
-    HIP_TRY(c, launch_table_score_frames(c->stream, fp, c->d_trect, c->d_toff, c->d_tpack, c->table_C, c->d_ft32, c->n_targets, c->d_tg_t32c, c->d_tg_ltotal,
+    HIP_TRY(c, launch_table_score_frames(c->stream, fp, c->d_tcount, c->d_toff, c->d_tgoff, c->d_tgval, c->table_C, c->d_ft32, c->n_targets, c->d_tg_t32c, c->d_tg_ltotal,
                                          c->d_tg_scores, c->d_tg_best));
     std::vector<double> best(2 * N);
     HIP_TRY(c, hipMemcpyAsync(best.data(), c->d_tg_best, 2 * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));

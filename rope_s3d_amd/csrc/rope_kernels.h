@@ -177,23 +177,25 @@ hipError_t launch_empty(int loss, hipStream_t st, const FrameParams &fp, const u
                         uint64_t *empty_sums, uint64_t *total, int n_frames = 1);
 hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total_empty, int C, int loss, int n_render,
                            double n_pix, const LinkFlags &lf, double *err /* C + 2: errors, best error, best index */);
-// the stored lookup table keeps of every row the rectangle that holds its samples: dense rows (C x ch x cw) -> rects / offs /
-// packed (values of row k at packed + offs[k], a multiple of four floats); *used = floats taken in packed (zero it first)
-hipError_t launch_table_pack(hipStream_t st, int cw, int ch, const float *table, int C, ushort4 *rects, unsigned long long *offs,
-                             unsigned long long *used, float *packed);
+// The stored lookup table keeps, of every row, the groups of four consecutive samples of a crop row in which anything was drawn:
+// counts[k] groups from offs[k] on in goff (offset of the group's first sample inside the crop) / gval (its four values).
+// launch_table_count: dense rows (C x ch x cw) -> counts / offs, *used = groups in all (zero it first); launch_table_fill writes them.
+hipError_t launch_table_count(hipStream_t st, int cw, int ch, const float *table, int C, uint32_t *counts, unsigned long long *offs,
+                              unsigned long long *used);
+hipError_t launch_table_fill(hipStream_t st, int cw, int ch, const float *table, int C, const unsigned long long *offs, uint32_t *goff, float4 *gval);
 // score every row of a stored lookup table against the float32 target plane
-// t32c: scratch of crop_h x crop_w floats (the cropped target, rebuilt by every call); total: ROPE_SUM_WORDS words of scratch
-hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
-                              const float *packed, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums);
+// t32c: scratch of crop_h x crop_w + 4 floats (the cropped target, rebuilt by every call); total: ROPE_SUM_WORDS words of scratch
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const uint32_t *counts, const unsigned long long *offs, const uint32_t *goff,
+                              const float4 *gval, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums);
 // batches over several frames' targets (rope_eval_targets / rope_lookup_score_targets)
 hipError_t launch_finalize_frames(hipStream_t st, uint64_t *sums, const uint64_t *totals /* frames x SUM_WORDS */, const int32_t *frame_of,
                                   const LinkFlags *flags /* per frame, device */, int C, int loss, int n_render, double n_pix, double *err /* C */);
 // first argmin of n_sets sets of C doubles: best[2 k] error, best[2 k + 1] index
 hipError_t launch_argmin_sets(hipStream_t st, const double *err, int C, int n_sets, double *best);
-// the stored table against the float32 planes of n_frames frames: t32c n_frames x crop floats of scratch, totals n_frames x
+// the stored table against the float32 planes of n_frames frames: t32c n_frames x crop + 4 floats of scratch, totals n_frames x
 // SUM_WORDS of scratch, scores n_frames x C, best n_frames x 2 (score, row)
-hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
-                                     const float *packed, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,
+hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const uint32_t *counts, const unsigned long long *offs,
+                                     const uint32_t *goff, const float4 *gval, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,
                                      double *scores, double *best);
 hipError_t launch_resolve(hipStream_t st, const uint32_t *key, int n, const FrameParams &fp, float *depth, uint8_t *ids);
 

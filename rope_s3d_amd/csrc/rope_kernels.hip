@@ -1382,9 +1382,9 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
 // ------------------------------------------------------------- lookup table -----
 // Lookup stage against a stored table (predict.py:165-171): per row k of the table, the exact sums of |T - sqrtD_k| in Q32
 // over the crop.  The crop is the box of every pose of the grid; one pose covers a fraction of it, and where a row holds
-// nothing the term is |T - 0|, the same for every row.  So a row is stored as the rectangle that holds its samples
-// (table_pack_kernel), the sums of |T| over the whole crop are taken once per frame (crop_total_kernel), and a row's sums are
-// total + sum over its rectangle of (|T - D| - |T|) — integers, so exactly the sums over the whole crop.
+// nothing the term is |T - 0|, the same for every row.  So a row is stored as the groups of samples that hold something
+// (table_count_kernel / table_fill_kernel), the sums of |T| over the whole crop are taken once per frame (crop_total_kernel), and
+// a row's sums are total + sum over its groups of (|T - D| - |T|) — integers, so exactly the sums over the whole crop.
 
 // One workgroup: the crop of the target plane as one contiguous array laid out like the crop (no index arithmetic on the
 // image per sample later), and the sums of |T| over it.
@@ -1423,65 +1423,82 @@ crop_total_kernel(FrameParams fp, const float *__restrict__ t32, float *__restri
     }
 }
 
-// Build time: the rectangle of dense row k that holds anything, copied to packed[] at an offset reserved with one atomic (a
-// multiple of four floats: 16-byte loads later).  rects[k] = (first row, first column, rows, columns) inside the crop.
+// Build time.  A dense row (the cropped sqrt-depth image of one grid pose) is mostly zeros: the crop is the box of every pose of the
+// grid together, one pose covers a fraction of it, and the robot a fraction of its own bounding box.  A sample that holds nothing
+// contributes |T - 0| - |T| = 0 to the row's sums, exactly — so the stored table keeps only the GROUPS of four consecutive samples
+// of a crop row (columns 4k .. 4k+3) in which anything was drawn: per group the offset of its first sample inside the crop and
+// its four values (columns past the crop's edge read as 0).  table_count_kernel counts a row's groups and reserves their place,
+// table_fill_kernel writes them (in any order: the sums are integers).
 __global__ void __launch_bounds__(256)
-table_pack_kernel(int cw, int ch, const float *__restrict__ table, ushort4 *__restrict__ rects, unsigned long long *__restrict__ offs,
-                  unsigned long long *__restrict__ used, float *__restrict__ packed)
+table_count_kernel(int cw, int ch, const float *__restrict__ table, uint32_t *__restrict__ counts, unsigned long long *__restrict__ offs,
+                   unsigned long long *__restrict__ used)
 {
-    __shared__ int s_box[4];
-    __shared__ unsigned long long s_off;
-    const int n = cw * ch;
-    const float *row = table + (size_t)blockIdx.x * n;
-    if (threadIdx.x == 0) { s_box[0] = ch; s_box[1] = -1; s_box[2] = cw; s_box[3] = -1; }
+    __shared__ int s_n;
+    const int gw = (cw + 3) >> 2, n_groups = gw * ch;
+    const float *row = table + (size_t)blockIdx.x * cw * ch;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    int r0 = ch, r1 = -1, c0 = cw, c1 = -1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        if (row[i] != 0.0f) {
-            const int r = i / cw, c = i - r * cw;
-            r0 = min(r0, r); r1 = max(r1, r); c0 = min(c0, c); c1 = max(c1, c);
-        }
-    if (r1 >= 0) { atomicMin(&s_box[0], r0); atomicMax(&s_box[1], r1); atomicMin(&s_box[2], c0); atomicMax(&s_box[3], c1); }
-    __syncthreads();
-    r0 = s_box[0]; r1 = s_box[1]; c0 = s_box[2]; c1 = s_box[3];
-    const int h = r1 >= r0 ? r1 - r0 + 1 : 0, w = h ? c1 - c0 + 1 : 0, m = h * w;
-    if (threadIdx.x == 0) {
-        s_off = m ? atomicAdd(used, (unsigned long long)((m + 3) & ~3)) : 0ull;
-        rects[blockIdx.x] = make_ushort4((unsigned short)(h ? r0 : 0), (unsigned short)(h ? c0 : 0), (unsigned short)h, (unsigned short)w);
-        offs[blockIdx.x] = s_off;
+    int mine = 0;
+    for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        const int r = g / gw, c = 4 * (g - r * gw);
+        bool any = false;
+        for (int j = 0; j < 4; j++) any = any || (c + j < cw && row[(size_t)r * cw + c + j] != 0.0f);
+        mine += any;
     }
+    if (mine) atomicAdd(&s_n, mine);
     __syncthreads();
-    float *dst = packed + s_off;
-    for (int i = threadIdx.x; i < ((m + 3) & ~3); i += blockDim.x) {
-        const int r = i / max(w, 1), c = i - r * w;
-        dst[i] = i < m ? row[(size_t)(r0 + r) * cw + c0 + c] : 0.0f;
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = (uint32_t)s_n;
+        offs[blockIdx.x] = s_n ? atomicAdd(used, (unsigned long long)s_n) : 0ull;
     }
 }
 
-// One table row against one cropped target: lds[0..3] += sum over the row's rectangle of |T - D| minus sum of |T| (words S1, AA, AB,
-// BB), modulo 2^64 (the true value of total + s is not negative).  lds cleared and the workgroup synchronised by the caller.
-__device__ static inline void table_row_delta(const ushort4 rc, const float4 *__restrict__ row4, const float *__restrict__ t32c, int cw, uint64_t *lds)
+__global__ void __launch_bounds__(256)
+table_fill_kernel(int cw, int ch, const float *__restrict__ table, const unsigned long long *__restrict__ offs, uint32_t *__restrict__ goff,
+                  float4 *__restrict__ gval)
 {
-    const int r0 = rc.x, c0 = rc.y, w = rc.w, m = (int)rc.z * (int)rc.w;
+    __shared__ int s_n;
+    const int gw = (cw + 3) >> 2, n_groups = gw * ch;
+    const float *row = table + (size_t)blockIdx.x * cw * ch;
+    const unsigned long long base = offs[blockIdx.x];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        const int r = g / gw, c = 4 * (g - r * gw);
+        float v[4];
+        bool any = false;
+        for (int j = 0; j < 4; j++) { v[j] = c + j < cw ? row[(size_t)r * cw + c + j] : 0.0f; any = any || v[j] != 0.0f; }
+        if (!any) continue;
+        const int pos = atomicAdd(&s_n, 1);
+        goff[base + pos] = (uint32_t)(r * cw + c);
+        gval[base + pos] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// One group against one cropped target: s += sum of |T - D| minus sum of |T| over its four samples (words S1, AA, AB, BB), modulo
+// 2^64.  The target array is readable three floats past its end (a group at the crop's right edge holds zeros there, and what it
+// reads of the next row cancels).
+__device__ static inline void table_group_delta(uint32_t off, const float4 d, const float *__restrict__ t32c, uint64_t *s)
+{
+    const float t0 = t32c[off], t1 = t32c[off + 1], t2 = t32c[off + 2], t3 = t32c[off + 3];
+    acc_sq<false>(s, q32_of_f32(fabsf(t0 - d.x))); acc_sq<true>(s, q32_of_f32(fabsf(t0 - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t1 - d.y))); acc_sq<true>(s, q32_of_f32(fabsf(t1 - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t2 - d.z))); acc_sq<true>(s, q32_of_f32(fabsf(t2 - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t3 - d.w))); acc_sq<true>(s, q32_of_f32(fabsf(t3 - 0.0f)));
+}
+
+__global__ void __launch_bounds__(256)
+table_score_kernel(const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ offs, const uint32_t *__restrict__ goff,
+                   const float4 *__restrict__ gval, const float *__restrict__ t32c, const uint64_t *__restrict__ total, uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t lds[4];
+    if (threadIdx.x < 4) lds[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = (int)counts[blockIdx.x];
+    const unsigned long long base = offs[blockIdx.x];
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
-    const float inv_w = 1.0f / (float)max(w, 1);
-    auto one = [&](int i, float d) {
-        if (i >= m) return;
-        // i / w without an integer division: (i + 0.5) / w is at least 0.5 / w away from an integer and the float product is off
-        // by less than that for i < 2^22; the two corrections make it exact for any crop
-        int r = (int)(((float)i + 0.5f) * inv_w);
-        r -= (r * w > i);
-        r += ((r + 1) * w <= i);
-        const int c = i - r * w;
-        const float t = t32c[(r0 + r) * cw + c0 + c];
-        acc_sq<false>(s, q32_of_f32(fabsf(t - d)));
-        acc_sq<true>(s, q32_of_f32(fabsf(t - 0.0f)));
-    };
-    for (int i4 = threadIdx.x; 4 * i4 < m; i4 += blockDim.x) {
-        const float4 d = row4[i4];
-        one(4 * i4, d.x); one(4 * i4 + 1, d.y); one(4 * i4 + 2, d.z); one(4 * i4 + 3, d.w);
-    }
+    for (int g = threadIdx.x; g < n; g += blockDim.x) table_group_delta(goff[base + g], gval[base + g], t32c, s);
     const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1490,18 +1507,7 @@ __device__ static inline void table_row_delta(const ushort4 rc, const float4 *__
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds[k], (unsigned long long)v);
     }
-}
-
-__global__ void __launch_bounds__(256)
-table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned long long *__restrict__ offs, const float *__restrict__ packed,
-                   const float *__restrict__ t32c, const uint64_t *__restrict__ total, uint64_t *__restrict__ sums)
-{
-    __shared__ uint64_t lds[4];
-    if (threadIdx.x < 4) lds[threadIdx.x] = 0;
     __syncthreads();
-    table_row_delta(rects[blockIdx.x], reinterpret_cast<const float4 *>(packed + offs[blockIdx.x]), t32c, cw, lds);
-    __syncthreads();
-    const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
     if (threadIdx.x < ROPE_SUM_WORDS) {
         uint64_t v = 0;
         for (int k = 0; k < 4; k++) if ((int)threadIdx.x == words[k]) v = total[words[k]] + lds[k];
@@ -1511,36 +1517,41 @@ table_score_kernel(int cw, const ushort4 *__restrict__ rects, const unsigned lon
 
 __device__ static inline double mean_std_parts(const uint64_t *s, double N, double &m1);
 
-// The same for the targets of many frames (rope_lookup_score_targets): grid = (table rows, frame chunks); a workgroup takes its
-// row against the cropped target of every frame of its chunk — the row's values come from HBM once and from the cache afterwards —
-// and writes the finished lookup score (finalize_one's steps for ROPE_LOSS_LOOKUP on the same sums: same bits) to
-// scores[frame x rows + row].
+// The same for the targets of many frames (rope_lookup_score_targets): grid = (table rows, frame chunks), and inside a workgroup
+// ONE WAVE per (row, frame) pair — a row's few hundred groups are a handful per lane, so a pair needs no barrier and no LDS: the
+// lanes' partial sums meet by lane exchange and lane 0 writes the finished lookup score (finalize_one's steps for ROPE_LOSS_LOOKUP
+// on the same sums: same bits) to scores[frame x rows + row].  The row's groups come from HBM once and from the cache for the
+// other frames.
 __global__ void __launch_bounds__(256)
-table_score_frames_kernel(int cw, int crop_px, const ushort4 *__restrict__ rects, const unsigned long long *__restrict__ offs,
-                          const float *__restrict__ packed, const float *__restrict__ t32c /* frames x crop_px */,
+table_score_frames_kernel(int crop_px, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ offs,
+                          const uint32_t *__restrict__ goff, const float4 *__restrict__ gval, const float *__restrict__ t32c /* frames x crop_px */,
                           const uint64_t *__restrict__ totals /* frames x ROPE_SUM_WORDS */, int n_frames, double n_pix,
                           double *__restrict__ scores)
 {
-    __shared__ uint64_t lds[4];
-    const ushort4 rc = rects[blockIdx.x];
-    const float4 *row4 = reinterpret_cast<const float4 *>(packed + offs[blockIdx.x]);
+    const int n = (int)counts[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long base = offs[blockIdx.x];
     const int per = (n_frames + (int)gridDim.y - 1) / (int)gridDim.y, f_lo = (int)blockIdx.y * per, f_hi = min(f_lo + per, n_frames);
-    for (int f = f_lo; f < f_hi; f++) {
-        if (threadIdx.x < 4) lds[threadIdx.x] = 0;
-        __syncthreads();
-        table_row_delta(rc, row4, t32c + (size_t)f * crop_px, cw, lds);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t s[ROPE_SUM_WORDS];
+    for (int f = f_lo + wave; f < f_hi; f += 4) {
+        const float *__restrict__ t = t32c + (size_t)f * crop_px;
+        uint64_t s[ROPE_SUM_WORDS];
 #pragma unroll
-            for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
+        for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
+        for (int g = lane; g < n; g += 64) table_group_delta(goff[base + g], gval[base + g], t, s);
+#pragma unroll
+        for (int k = SUM_S1; k <= SUM_BB; k++) {
+            uint64_t v = s[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            s[k] = v;
+        }
+        if (lane == 0) {
             const uint64_t *total = totals + (size_t)f * ROPE_SUM_WORDS;
-            s[SUM_S1] = total[SUM_S1] + lds[0]; s[SUM_AA] = total[SUM_AA] + lds[1]; s[SUM_AB] = total[SUM_AB] + lds[2]; s[SUM_BB] = total[SUM_BB] + lds[3];
+#pragma unroll
+            for (int k = SUM_S1; k <= SUM_BB; k++) s[k] += total[k];
             double m1;
             const double sd = mean_std_parts(s, n_pix, m1);
             scores[(size_t)f * gridDim.x + blockIdx.x] = m1 * sd;
         }
-        __syncthreads();
     }
 }
 
@@ -1845,32 +1856,39 @@ hipError_t launch_argmin_sets(hipStream_t st, const double *err, int C, int n_se
     return hipGetLastError();
 }
 
-hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
-                                     const float *packed, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,
+hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const uint32_t *counts, const unsigned long long *offs,
+                                     const uint32_t *goff, const float4 *gval, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,
                                      double *scores, double *best)
 {
     const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
     hipLaunchKernelGGL(crop_total_kernel, dim3(n_frames), dim3(1024), 0, st, fp, t32, t32c, totals);
-    // enough workgroups to fill the chip when the table is small; otherwise a row meets every frame in one workgroup
-    const int chunks = std::max(1, std::min(n_frames, (4096 + C - 1) / C));
-    hipLaunchKernelGGL(table_score_frames_kernel, dim3(C, chunks), dim3(256), 0, st, cw, cw * ch, rects, offs, packed, t32c, totals, n_frames,
+    // a workgroup takes four frames at a time (a wave each): enough workgroups to fill the chip when the table is small; otherwise
+    // a row meets every frame in one workgroup
+    const int chunks = std::max(1, std::min((n_frames + 3) / 4, (4096 + C - 1) / C));
+    hipLaunchKernelGGL(table_score_frames_kernel, dim3(C, chunks), dim3(256), 0, st, cw * ch, counts, offs, goff, gval, t32c, totals, n_frames,
                        (double)cw * (double)ch, scores);
     hipLaunchKernelGGL(argmin_sets_kernel, dim3(n_frames), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, scores, C, best);
     return hipGetLastError();
 }
 
-hipError_t launch_table_pack(hipStream_t st, int cw, int ch, const float *table, int C, ushort4 *rects, unsigned long long *offs,
-                             unsigned long long *used, float *packed)
+hipError_t launch_table_count(hipStream_t st, int cw, int ch, const float *table, int C, uint32_t *counts, unsigned long long *offs,
+                              unsigned long long *used)
 {
-    hipLaunchKernelGGL(table_pack_kernel, dim3(C), dim3(256), 0, st, cw, ch, table, rects, offs, used, packed);
+    hipLaunchKernelGGL(table_count_kernel, dim3(C), dim3(256), 0, st, cw, ch, table, counts, offs, used);
     return hipGetLastError();
 }
 
-hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const ushort4 *rects, const unsigned long long *offs,
-                              const float *packed, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums)
+hipError_t launch_table_fill(hipStream_t st, int cw, int ch, const float *table, int C, const unsigned long long *offs, uint32_t *goff, float4 *gval)
+{
+    hipLaunchKernelGGL(table_fill_kernel, dim3(C), dim3(256), 0, st, cw, ch, table, offs, goff, gval);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const uint32_t *counts, const unsigned long long *offs, const uint32_t *goff,
+                              const float4 *gval, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums)
 {
     hipLaunchKernelGGL(crop_total_kernel, dim3(1), dim3(1024), 0, st, fp, t32, t32c, total);
-    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, fp.c1 - fp.c0 + 1, rects, offs, packed, t32c, total, sums);
+    hipLaunchKernelGGL(table_score_kernel, dim3(C), dim3(256), 0, st, counts, offs, goff, gval, t32c, total, sums);
     return hipGetLastError();
 }
 

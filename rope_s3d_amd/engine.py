@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
     'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
     'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
-    'rope_prepare_synthetic')
+    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP, STAGE_TSWEEP = 0, 1, 2, 3, 4
@@ -106,6 +106,10 @@ def load_library(path: str = None):
     lib.rope_eval_targets.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.rope_lookup_score_targets.argtypes = [vp, vp, vp, vp]
     lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
+    lib.rope_host_alloc.argtypes = [C.c_size_t]
+    lib.rope_host_alloc.restype = C.c_void_p
+    lib.rope_host_free.argtypes = [vp]
+    lib.rope_host_free.restype = None
     lib.rope_prepare_synthetic.argtypes = [vp, C.c_int64, vp, i32, C.c_int64, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -133,6 +137,21 @@ def pack_target(depth: np.ndarray, mask_bits: np.ndarray = None) -> np.ndarray:
     if mask_bits is not None:
         q |= np.asarray(mask_bits, np.uint64) << np.uint64(40)
     return np.ascontiguousarray(q)
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """np.empty in page-locked host memory (rope_host_alloc): planes handed to set_target(s) from it reach the device in one
+    transfer.  Falls back to ordinary memory when the runtime refuses.  The memory lives as long as the array (or any view of it)."""
+    import weakref
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    lib = load_library()
+    ptr = lib.rope_host_alloc(n) if n else None
+    if not ptr:
+        return np.empty(shape, dtype)
+    buf = (C.c_ubyte * n).from_address(ptr)
+    weakref.finalize(buf, lib.rope_host_free, C.c_void_p(ptr))
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def prepare_synthetic(color: np.ndarray, depth: np.ndarray, f: int, link_blue, n_lookup_links: int, tq: np.ndarray, lookup_f32: np.ndarray,

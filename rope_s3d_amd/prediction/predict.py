@@ -91,8 +91,10 @@ class Predictor:
     SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
     NATIVE_PREPARE = True   # synthetic path: prepare() as one pass in the library (rope_prepare_synthetic); False: the numpy steps, same arrays
-    BATCH = 64         # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
-                       # (rope_predict_batch); 1: frame after frame (rope_predict).  Same angles either way.
+    BATCH = None       # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
+                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..256 (256 at the default
+                       # 160x90, 64 at 640x480); 1: frame after frame (rope_predict).  Same angles either way.
+    BATCH_BYTES = 256 << 20
 
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
@@ -308,7 +310,7 @@ class Predictor:
                 masks[link] = m
         return self._pack_target(target_depth, lookup_depth, masks, target_color)       # target_color: `output` of predict.py:469
 
-    def _prepare_synthetic_native(self, target_color, target_depth, tq=None, lookup_f32=None, flags=None, tgt_depth=None):
+    def _prepare_synthetic_native(self, target_color, target_depth, tq=None, lookup_f32=None, flags=None, tgt_depth=None, want_depth=True):
         """The synthetic path's prepare() as ONE pass in the library (rope_prepare_synthetic: the same taps, comparisons, counts and
         roundings as _downsample + _loadSynthetic + _pack_target), into the given arrays (slots of a batch) or fresh ones.  None when
         the frame's layout or the colour dictionary is not what that pass takes — the numpy steps do it then."""
@@ -324,7 +326,7 @@ class Predictor:
         tq = np.empty(shape, np.uint64) if tq is None else tq
         lookup_f32 = np.empty(shape, np.float32) if lookup_f32 is None else lookup_f32
         flags = np.zeros(8, np.uint8) if flags is None else flags
-        tgt_depth = np.empty(shape, np.float64) if tgt_depth is None else tgt_depth
+        tgt_depth = np.empty(shape, np.float64) if (tgt_depth is None and want_depth) else tgt_depth
         blue = [int(self.color_dict[k][0]) for k in self.link_names]
         if not prepare_synthetic(color, depth, f, blue, LOOKUP_NUM_RENDERED, tq, lookup_f32, flags, tgt_depth):
             return None
@@ -364,6 +366,18 @@ class Predictor:
         return self._run_planes(np.stack([p.tq for p in prepared]), np.stack([p.lookup_f32 for p in prepared]),
                                 np.stack([p.flags for p in prepared]), ts)
 
+    def _plane_set(self, which: int, b: int, H: int, W: int, want_ts: bool):
+        """One of the two sets of stacked target planes for `b` frames (page-locked host memory, kept between calls)."""
+        from ..engine import pinned_empty
+        pool = self.__dict__.setdefault('_planes', {})
+        key = (which, b, H, W, want_ts)
+        if key not in pool:
+            for old in [k for k in pool if k[0] == which]:
+                del pool[old]
+            pool[key] = (pinned_empty((b, H, W), np.uint64), pinned_empty((b, H, W), np.float32), np.zeros((b, 8), np.uint8),
+                         pinned_empty((b, H, W), np.float32) if want_ts else None)
+        return pool[key]
+
     def _batch_ok(self) -> bool:
         """The current stage list can walk many frames in lockstep (rope_predict_batch)."""
         return self.NATIVE and not self.preview and not self.reference_table_aliasing and self._native_stages() is not None
@@ -400,7 +414,7 @@ class Predictor:
 
         def fill(planes, k, i):
             tq, t32, fl, ts = planes
-            prep = self._prepare_synthetic_native(target_colors[i], target_depths[i], tq[k], t32[k], fl[k]) if self.NATIVE_PREPARE else None
+            prep = self._prepare_synthetic_native(target_colors[i], target_depths[i], tq[k], t32[k], fl[k], want_depth=want_ts) if self.NATIVE_PREPARE else None
             if prep is None:
                 prep = self.prepare(target_colors[i], target_depths[i])
                 tq[k], t32[k], fl[k] = prep.tq, prep.lookup_f32, prep.flags
@@ -410,18 +424,20 @@ class Predictor:
         # the segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order
         workers = max(1, min(8, cpu_budget() - 1)) if self.synthetic else 1
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            def submit(g):
-                b = g[1] - g[0]
-                planes = (np.empty((b, H, W), np.uint64), np.empty((b, H, W), np.float32), np.zeros((b, 8), np.uint8),
-                          np.empty((b, H, W), np.float32) if want_ts else None)
-                return planes, [pool.submit(fill, planes, k, g[0] + k) for k in range(b)]
-            nxt = submit(groups[0])
+            def submit(k):
+                lo_, hi_ = groups[k]
+                b = hi_ - lo_
+                # two sets of planes in page-locked memory, taken in turn: group k+1 is written while group k is on the GPU
+                tq, t32, fl, ts = self._plane_set(k & 1, min(batch, n), H, W, want_ts)
+                planes = (tq[:b], t32[:b], fl[:b], None if ts is None else ts[:b])
+                return planes, [pool.submit(fill, planes, j, lo_ + j) for j in range(b)]
+            nxt = submit(0)
             for k, (lo, hi) in enumerate(groups):
                 planes, jobs = nxt
                 for j in jobs:
                     j.result()
                 if k + 1 < len(groups):
-                    nxt = submit(groups[k + 1])
+                    nxt = submit(k + 1)
                 if camera_poses is not None and np.any(np.asarray(camera_poses[lo]) != self.camera_pose):
                     self.changeCameraPose(camera_poses[lo])
                 out[lo:hi] = self._run_planes(*planes)
@@ -437,6 +453,8 @@ class Predictor:
         if n == 0:
             return out
         batch = self.BATCH if batch is None else int(batch)
+        if batch is None:                              # 12 bytes of target planes per pixel and frame (uint64 + float32)
+            batch = int(min(256, max(16, self.BATCH_BYTES // (12 * self.intrinsics.width * self.intrinsics.height))))
         self._setStages()
         if batch > 1 and n > 1 and self._batch_ok():
             return self._run_many_batched(target_colors, target_depths, camera_poses, batch)

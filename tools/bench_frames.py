@@ -22,7 +22,8 @@ div = int(sys.argv[4]) if len(sys.argv) > 4 else None
 sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, intr, ds, 'SLU', noise=False, seed=1, lookup_divisions=div)
 p = sp.predictor
 p.NATIVE = os.environ.get('ROPE_NATIVE', '1') != '0'       # 0: the Python stage loop instead of rope_predict
-p.BATCH = int(os.environ.get('ROPE_BATCH', p.BATCH))         # run_many: frames in lockstep per device batch (1: frame after frame)
+if 'ROPE_BATCH' in os.environ:
+    p.BATCH = int(os.environ['ROPE_BATCH'])                # run_many: frames in lockstep per device batch (1: frame after frame; default: by plane size)
 print(f"stage loop: {'rope_predict (C++)' if p.NATIVE else 'Python'}")
 print(f"render {p.intrinsics.width}x{p.intrinsics.height}, lookup grid {len(p.lookup_angles)} poses, crop {list(p.lookup_crop)}")
 lim = sp.urdf_reader.joint_limits
@@ -49,7 +50,7 @@ if int(os.environ.get('ROPE_POOL', '0')) > 1:                # PredictorPool: k 
     p = pool
 elif os.environ.get('ROPE_PREFETCH', '0') != '0':             # Predictor.run_many: BATCH frames in lockstep (BATCH 1: frame i+1 prepared while frame i is on the GPU)
     res[0] = poses
-    p.run_many([c for c, _ in frames[:2 * p.BATCH]], [d for _, d in frames[:2 * p.BATCH]])      # warm-up: buffers of a batch's size
+    p.run_many([c for c, _ in frames[:2 * (p.BATCH or 256)]], [d for _, d in frames[:2 * (p.BATCH or 256)]])      # warm-up: buffers of a batch's size
     p.evaluations = 0
     t0 = time.perf_counter()
     res[1] = p.run_many([c for c, _ in frames], [d for _, d in frames])
