@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# dmabuf IPC: what RCCL (and any sharing of device memory between the ranks' processes) needs on this driver; set before torch
+# is imported, for ranks started by the driver's launcher as much as for the ones self_launch starts
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -168,13 +172,16 @@ def main():
     device = int(os.environ.get('ROPE_FORCE_DEVICE', local_rank))
     torch.cuda.set_device(device)
     coll_dev = torch.device('cuda', device) if args.backend == 'nccl' else torch.device('cpu')
-    if world > 1:
+    # ROPE_DIST_ALWAYS: also a world of one goes through the process group and its collectives (tests/test_gpu_runtime.py: RCCL
+    # itself gets executed on a one-GPU box)
+    use_dist = world > 1 or bool(os.environ.get('ROPE_DIST_ALWAYS'))
+    if use_dist:
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', device))
         else:
             dist.init_process_group(args.backend)
 
-    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ranks_seen = dist.get_world_size() if use_dist else 1
     if ranks_seen != args.gpus:
         raise SystemExit(f"bench.py: process group holds {ranks_seen} ranks, --gpus says {args.gpus}")
 
@@ -232,7 +239,7 @@ def main():
     e.upload_candidates(cand)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -241,7 +248,7 @@ def main():
     e.sync()
 
     best = torch.zeros(8 if args.split_candidates else 6, dtype=torch.float64, device=coll_dev)
-    if world > 1:                                # part of the warm-up: the collective's first call sets up its channels
+    if use_dist:                                 # part of the warm-up: the collective's first call sets up its channels
         dist.all_gather([torch.zeros_like(best) for _ in range(world)], best)
     barrier()
     t0 = time.perf_counter()
@@ -253,7 +260,7 @@ def main():
         best.copy_(torch.from_numpy(np.concatenate([cand[bi], [be, first + bi]])))
     else:
         best.copy_(torch.from_numpy(cand[bi]))
-    if world > 1:
+    if use_dist:
         gathered = [torch.zeros_like(best) for _ in range(world)]
         dist.all_gather(gathered, best)         # the single collective: final joint angles (+ score and index) over xGMI
         if args.split_candidates:               # global argmin: smallest error, then smallest index; NaN never wins
@@ -262,7 +269,7 @@ def main():
             be, bi = float(g[order[0], 6]), int(g[order[0], 7])
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -306,7 +313,7 @@ def main():
                        "candidates_per_step": C, "frames_per_rank": 1,
                        "parallelism": f"candidates of one frame /{world}" if args.split_candidates else f"frames x{world}",
                        "argmin_error": be, "argmin_index": bi},
-            "ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen, "collective": (args.backend if use_dist else None),
             "unshared_value": C / (kern_u['total'] * 1e-3) if kern_u else None,
             "unshared_note": "poses/s per GPU with rope_set_strategy(NO_LAYERS): links 0-2 drawn for every candidate instead of once "
                              "per distinct (S, L); same results bit for bit; measured after the timed region",
@@ -329,7 +336,7 @@ def main():
             gpu_err = e.download(want_err=True)[0]                 # errors of the last timed pass, outside the timed region
             out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C), gpu_err, loss, flags)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

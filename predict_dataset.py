@@ -11,6 +11,9 @@ Output: predictions_<dataset>.npy, as the reference (predict_dataset.py:47-49).
 import argparse
 import os
 
+# dmabuf IPC: what RCCL needs on this driver (bench.py says the same); before anything imports torch, whoever started the ranks
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import numpy as np
 
 from robotpose import Dataset, Grapher, Predictor
@@ -22,7 +25,9 @@ def run(args):
     # ROPE_FORCE_DEVICE / ROPE_DIST_BACKEND: rehearse the N>1 flow on a one-GPU box (all ranks on device 0, gloo)
     gpu = int(os.environ.get('ROPE_FORCE_DEVICE', local_rank))
     device = None
-    if world > 1:
+    # ROPE_DIST_ALWAYS: a world of one goes through the process group and the gather too (RCCL executed on a one-GPU box)
+    use_dist = world > 1 or bool(os.environ.get('ROPE_DIST_ALWAYS'))
+    if use_dist:
         import torch
         import torch.distributed as dist
         backend = os.environ.get('ROPE_DIST_BACKEND', 'nccl')
@@ -33,7 +38,8 @@ def run(args):
         else:
             dist.init_process_group(backend)
 
-    ds = Dataset(args.dataset)
+    from rope_s3d_amd.data.dataset import open_dataset
+    ds = open_dataset(args.dataset, gpu)                 # a stored set, or 'synthetic:<frames>[:<seed>[:<preset>]]' rendered as it is read
     kwargs = {}
     if getattr(args, 'segmenter', None) == 'maskrcnn':
         # BASELINE configs[2]: the segmentation stage on PyTorch-ROCm in front of the engine (predict.py:94-98,416).
@@ -99,11 +105,13 @@ def run(args):
         else:
             out[start - lo:end - lo] = am.run_many(og_imgs, dms, cam_poses, batch=getattr(args, 'batch', None))
     reader.shutdown()
-    full = gather_rows(out, ds.length, device=device)
+    full = gather_rows(out, ds.length, device=device, single_rank_too=use_dist)
     if rank == 0:
-        np.save(f'predictions_{os.path.basename(os.path.normpath(args.dataset))}.npy', full)
+        if use_dist:
+            print(f"{ds.length} frames of {world} rank(s) gathered over {os.environ.get('ROPE_DIST_BACKEND', 'nccl')}")
+        np.save(f"predictions_{os.path.basename(os.path.normpath(args.dataset)).replace(':', '_')}.npy", full)
         Grapher(args.angs, full, np.copy(ds.angles)).plot()
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

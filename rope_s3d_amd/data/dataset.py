@@ -133,6 +133,88 @@ def make_synthetic_dataset(name: str, n_frames: int, base_intrin: str = '640_480
                          extra_attrs={'synthetic': True, 'color_dict': r.color_dict})
 
 
+class _LazyFrames:
+    """Sequence of frames rendered when they are read: ds.og_img[i], ds.og_img[a:b] (a fresh array each time, like an HDF5 slice)."""
+
+    def __init__(self, owner, what: int, shape, dtype):
+        self._owner, self._what, self.shape, self.dtype = owner, what, (owner.length,) + tuple(shape), np.dtype(dtype)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            idx = range(*key.indices(self.shape[0]))
+            out = np.empty((len(idx),) + self.shape[1:], self.dtype)
+            for k, i in enumerate(idx):
+                out[k] = self._owner.frame(i)[self._what]
+            return out
+        i = int(key)
+        if i < 0:
+            i += self.shape[0]
+        if not 0 <= i < self.shape[0]:
+            raise IndexError(i)
+        return self._owner.frame(i)[self._what].astype(self.dtype, copy=True)
+
+
+class SyntheticDataset:
+    """The frames make_synthetic_dataset(seed=...) would write, rendered on the GPU as they are read instead of stored: frame f uses
+    default_rng(seed + f), pose uniform in the joint limits of `do_angles`.  Same attribute surface as Dataset; a
+    10 000-frame 640x480 set (BASELINE configs[3]) is 34 GB on disk and nothing here.
+    Name form for the callers that take a dataset name: 'synthetic:<frames>[:<seed>[:<intrinsics preset>]]'."""
+
+    PREFIX = 'synthetic:'
+
+    def __init__(self, n_frames: int, base_intrin: str = '640_480_color', camera_pose=None, do_angles: str = 'SLU', seed: int = 7919,
+                 device: int = 0):
+        import threading
+        from ..constants import DEFAULT_CAMERA_POSE
+        from ..simulation.render import Renderer
+        from ..utils import str_to_arr
+        pose = np.asarray(DEFAULT_CAMERA_POSE if camera_pose is None else camera_pose, float)
+        self._r = Renderer('seg', pose, base_intrin, device=device)
+        self._lock = threading.Lock()                    # one engine context: frames are rendered one at a time
+        self._last = (None, None)
+        lim = self._r.robot.joint_limits
+        self.length, self.name = int(n_frames), f'{self.PREFIX}{n_frames}:{seed}:{base_intrin}'
+        self.angles = np.stack([np.random.default_rng(seed + f).uniform(lim[:, 0], lim[:, 1]) * str_to_arr(do_angles) for f in range(n_frames)])
+        self.camera_pose = np.tile(pose, (n_frames, 1))
+        self.positions = np.zeros((n_frames, 6, 3))
+        H, W = self._r.resolution
+        self.og_img, self.depthmaps = _LazyFrames(self, 0, (H, W, 3), np.uint8), _LazyFrames(self, 1, (H, W), np.float64)
+        self.preview_img = None
+        self.intrinsics = str(self._r.intrinsics)
+        self.og_resolution = [H, W]
+        self.attrs = {'name': self.name, 'length': self.length, 'resolution': [H, W], 'color_intrinsics': self.intrinsics,
+                      'synthetic': True, 'color_dict': self._r.color_dict}
+        self.dataset_dir = self.name
+
+    @classmethod
+    def from_name(cls, name: str, device: int = 0):
+        parts = name[len(cls.PREFIX):].split(':')
+        return cls(int(parts[0]), parts[2] if len(parts) > 2 else '640_480_color', seed=int(parts[1]) if len(parts) > 1 else 7919, device=device)
+
+    def frame(self, i: int):
+        with self._lock:
+            if self._last[0] != i:                       # colour and depth of a frame are asked for one after the other
+                self._r.setJointAngles(self.angles[i])
+                self._last = (i, self._r.render())
+            return self._last[1]
+
+    def close(self):
+        pass
+
+    def __len__(self) -> int:
+        return self.length
+
+
+def open_dataset(name: str, device: int = 0):
+    """Dataset(name), or the frames of a 'synthetic:<frames>[:<seed>[:<preset>]]' name rendered on the fly."""
+    if isinstance(name, str) and name.startswith(SyntheticDataset.PREFIX):
+        return SyntheticDataset.from_name(name, device)
+    return Dataset(name)
+
+
 def write_h5_dataset(name: str, og_img, depthmaps, angles, camera_pose, color_intrinsics: str, positions=None,
                      extra_attrs: dict = None, compression_level: int = 4) -> str:
     """The same arrays as one `<name>/<name>.h5` in the reference's layout (building.py:195-242): what the reference's

@@ -55,6 +55,28 @@ class EngineError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch ships its own copy of libamdhip64 (SONAME libamdhip64.so.7, found through its RPATH);
+    librope_hip.so asks the loader for libamdhip64.so.7 and, loaded first, gets the system copy — a later `import torch` (the
+    segmentation stage: Predictor._load_segmenter imports maskrcnn after the engine exists) then brings a SECOND runtime into the
+    process, torch finds no GPU, and the rope_seg_* kernels would be handed streams and pointers of a runtime that is not theirs.
+    So when torch is installed and not yet loaded, its copy is mapped first: the loader then satisfies librope_hip.so — and
+    torch's own libraries later — with that one copy.  Nothing of torch is imported here."""
+    import sys
+    if 'torch' in sys.modules or os.environ.get('ROPE_SYSTEM_HIP_RUNTIME'):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        lib = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        if os.path.exists(lib):
+            C.CDLL(lib, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass                                             # no torch, or a torch without its own runtime: the system copy serves everyone
+
+
 def load_library(path: str = None):
     """dlopen librope_hip.so and declare the prototypes.  Does not touch the GPU."""
     global _lib
@@ -64,6 +86,7 @@ def load_library(path: str = None):
     if not os.path.exists(path):
         raise EngineUnavailable(f"{path} not found: build it with `python -m rope_s3d_amd.build` "
                                 "(hipcc, gfx950); the engine has no CPU fallback")
+    _share_torch_hip_runtime()
     try:
         lib = C.CDLL(path)
     except OSError as e:

@@ -21,14 +21,18 @@ def dist_env():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
-def gather_rows(local: np.ndarray, n_total: int, device=None) -> np.ndarray:
+def gather_rows(local: np.ndarray, n_total: int, device=None, single_rank_too: bool = False) -> np.ndarray:
     """All-gather per-rank result blocks (n_local, k) into (n_total, k) on every rank.
 
-    Blocks are padded to ceil(n/world) rows so that one fixed-size all_gather suffices."""
-    import torch
-    import torch.distributed as dist
+    Blocks are padded to ceil(n/world) rows so that one fixed-size all_gather suffices.  A world of one returns its block as it
+    is, unless single_rank_too asks for the collective anyway (one rank's rehearsal of the RCCL path)."""
     local = np.ascontiguousarray(local, np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:
+        return local[:n_total]
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not single_rank_too):
         return local[:n_total]
     world = dist.get_world_size()
     per = -(-n_total // world)

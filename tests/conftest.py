@@ -3,13 +3,8 @@ import sys
 
 import pytest
 
-try:
-    # PyTorch ships its own copy of the HIP runtime.  When it is imported AFTER librope_hip.so has brought in the system copy, the
-    # process holds two runtimes and torch finds no GPU; imported first, both use the one copy.  Tests that run the
-    # segmentation stage and the engine in one process depend on this order whatever subset of the files is selected.
-    import torch  # noqa: F401
-except ImportError:
-    pass
+# (engine.load_library maps PyTorch's copy of the HIP runtime before librope_hip.so, so the order of imports does not matter any
+# more: tests/test_gpu_runtime.py checks that in a fresh process.)
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
 if ROOT not in sys.path:

@@ -38,3 +38,16 @@ def test_bench_starts_two_ranks_itself():
     d = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--backend', 'gloo', '--no-cpu-baseline'], {'ROPE_FORCE_DEVICE': '0'})
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['config']['parallelism'] == 'frames x2'
     assert abs(d['value'] - 2 * 4096 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+
+
+def test_cfg5_candidate_split_over_two_ranks_finds_the_single_rank_argmin():
+    """BASELINE configs[4] geometry (mh50, 1280x720, 32^3 candidates of ONE frame) with the optional intra-frame split of SURVEY
+    §8e: two ranks take half the candidate grid each, all-gather (joint vector, best error, best index), global argmin — the
+    same row and the same error bits as the single-rank run."""
+    one = _run(['--workload', 'cfg5', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-unshared'])
+    two = _run(['--workload', 'cfg5', '--gpus', '2', '--split-candidates', '--steps', '2', '--warmup', '1', '--backend', 'gloo', '--no-cpu-baseline',
+                '--no-unshared'], {'ROPE_FORCE_DEVICE': '0'})
+    assert one['config']['candidates_per_step'] == 32768 and two['config']['candidates_per_step'] == 16384
+    assert two['n_gpus'] == 2 and two['scaling'] == 'strong' and two['config']['parallelism'] == 'candidates of one frame /2'
+    assert two['config']['argmin_index'] == one['config']['argmin_index']
+    assert two['config']['argmin_error'] == one['config']['argmin_error']          # JSON round-trips a double exactly

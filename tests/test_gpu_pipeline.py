@@ -88,3 +88,29 @@ def test_thousand_frames_with_the_mask_rcnn_stage(cfg2, monkeypatch):
     lim = helpers.robot().joint_limits
     ok = np.isfinite(full).all(1)
     assert ((full[ok] >= lim[:, 0] - 1e-9) & (full[ok] <= lim[:, 1] + 1e-9))[:, :3].all()       # whatever the masks, the stages stay inside the joint limits
+
+
+def test_cfg3_ten_thousand_frames_on_one_rank(tmp_path, monkeypatch):
+    """BASELINE configs[3] at its stated size on one rank: 10 000 synthetic 640x480 frames (rendered as they are read:
+    data.dataset.SyntheticDataset) through predict_dataset.run — frames in lockstep batches, the result block through the gather —
+    and a sample of the frames against Predictor.run one frame at a time: identical angles."""
+    from rope_s3d_amd import Predictor
+    from rope_s3d_amd.data.dataset import SyntheticDataset
+    n = int(os.environ.get('ROPE_CFG3_FRAMES', '10000'))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    pd = importlib.import_module('predict_dataset')
+    args = argparse.Namespace(dataset=f'synthetic:{n}:6100', angs='SLU', ds_factor=1, segmenter=None, weights=None, predictors=1,
+                              lookup_divisions=None, batch=None)
+    t0 = time.perf_counter()
+    full = pd.run(args)
+    dt = time.perf_counter() - t0
+    print(f"configs[3] on one rank: {n} frames of 640x480 in {dt:.1f} s = {n / dt:.0f} frames/s (rendering the frames and construction included)")
+    assert full.shape == (n, 6) and np.isfinite(full).all()
+    assert np.array_equal(np.load(tmp_path / f'predictions_synthetic_{n}_6100.npy'), full)
+    ds = SyntheticDataset(n, seed=6100)
+    err = np.abs(full - ds.angles)[:, :3]
+    assert np.median(err) < 0.02 and np.mean(err.max(1) < 0.1) > 0.8, (np.median(err), np.mean(err.max(1) < 0.1))
+    p = Predictor(ds_factor=1, camera_pose=ds.camera_pose[0], base_intrin=ds.intrinsics, color_dict=ds.attrs['color_dict'])
+    for i in np.random.default_rng(3).choice(n, 16, replace=False):
+        assert np.array_equal(p.run(ds.og_img[i], ds.depthmaps[i]).view(np.uint64), full[i].view(np.uint64)), i
