@@ -49,40 +49,36 @@ def slu_grid(limits, d):
     return ang
 
 
-def measured_traffic():
-    """HBM bytes per raster launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/summarize_prof.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE); null if absent."""
+PROFILE_ROUND = 'r03'          # profiles/<round>_pmc.json, <round>_valu_issue.json, <round>_kernel_clock.json
+
+
+def committed_profile(name, build_id):
+    """profiles/<name> if it belongs to the build being timed: tools/summarize_prof.py stamps the counters with the hash of the
+    sources they were taken on (rope_build_id of the library profiled).  -> (dict or None, stale?)"""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            return json.load(f)['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def measured_pmc():
-    """Per-launch PMC averages of the scoring kernel from the committed rocprofv3 passes of this round
-    (profiles/r02_pmc.json, tools/summarize_prof.py); {} if absent."""
-    for name in ('r02_pmc.json', 'r01_final_pmc.json'):
-        try:
-            with open(os.path.join(ROOT, 'profiles', name)) as f:
-                d = json.load(f)
-            return {k: v['avg_per_launch'] for k, v in d['counters'].items()}, name
-        except (OSError, KeyError, ValueError):
-            continue
-    return {}, None
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, False
+    if d.get('build_id') != build_id:
+        return None, True
+    return d, False
 
 
 def valu_issue_peak():
-    """Wave64 VALU instructions one SIMD retires per second at the raster kernel's occupancy (6 waves per SIMD), from the
-    committed micro-benchmark (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.json): (full-rate ops, a mix of the
-    kinds the kernel is made of), wall-clock based so that the clock the chip holds under load is already in it."""
+    """SIMD cycles one wave64 VALU instruction costs at the raster kernel's occupancy (6 waves per SIMD), from the committed
+    micro-benchmark (tools/valu_issue_bench.hip -> profiles/<round>_valu_issue.json): wall time of a launch of independent
+    instructions x the clock held inside that launch (s_memtime / s_memrealtime stamps).  -> {full-rate op, kernel-like mix,
+    half-rate op} cycles and the micro-benchmark's own clock; {} if absent.  (Independent of the library's build.)"""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_valu_issue.json')) as f:
-            kinds = {k['instruction']: k['wall_ns_per_wave_instruction_per_simd']['6'] for k in json.load(f)['kinds']}
+        with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_valu_issue.json')) as f:
+            kinds = {k['instruction']: k for k in json.load(f)['kinds']}
         mix = [v for k, v in kinds.items() if k.startswith('raster-like mix')][0]
-        return 1e9 / kinds['v_add_u32'], 1e9 / mix
+        return {'full_rate': kinds['v_add_u32']['cycles_per_wave_instruction_per_simd']['6'],
+                'half_rate': kinds['v_mul_i32_i24']['cycles_per_wave_instruction_per_simd']['6'],
+                'mix': mix['cycles_per_wave_instruction_per_simd']['6'], 'clock_ghz_microbench': mix['clock_ghz']['6']}
     except (OSError, KeyError, ValueError, IndexError):
-        return None, None
+        return {}
 
 
 def self_launch(args):
@@ -288,20 +284,37 @@ def main():
         raster_s = kern['raster'] * 1e-3
         achieved = b_cand * C / raster_s / 1e9
         default_wl = args.loss == 'depth' and args.workload == 'cfg1' and args.grid == 16
-        traffic = measured_traffic() if default_wl else None
-        pmc, pmc_file = measured_pmc() if default_wl else ({}, None)
-        peak_full, peak_mix = valu_issue_peak()
+        # Counters come from committed rocprofv3 passes, the times from this run: only counters taken on THIS build may be combined
+        # with them (a kernel edit changes the instruction count).  Stale files give nulls and "pmc_stale": true.
+        lib_id = eng.build_id()
+        traffic_d, stale_t = committed_profile('traffic.json', lib_id) if default_wl else (None, False)
+        pmc_d, stale_p = committed_profile(PROFILE_ROUND + '_pmc.json', lib_id) if default_wl else (None, False)
+        clock_d, stale_c = committed_profile(PROFILE_ROUND + '_kernel_clock.json', lib_id) if default_wl else (None, False)
+        traffic = traffic_d['hbm_bytes_per_launch'] if traffic_d else None
+        pmc = {k: v['avg_per_launch'] for k, v in pmc_d['counters'].items()} if pmc_d else {}
+        peak = valu_issue_peak()
         n_simd = 256 * 4
         valu = None
-        if pmc.get('SQ_INSTS_VALU') and peak_mix:
+        if pmc.get('SQ_INSTS_VALU') and peak:
             rate = pmc['SQ_INSTS_VALU'] / (kern['score'] * 1e-3)            # wave64 VALU instructions per second, whole chip
-            valu = {"bound": "valu_issue", "achieved": rate / 1e9, "peak": peak_mix * n_simd / 1e9, "unit": "G wave-instructions/s",
-                    "frac": rate / (peak_mix * n_simd), "peak_full_rate_ops": peak_full * n_simd / 1e9,
-                    "frac_of_full_rate_peak": rate / (peak_full * n_simd),
+            # the clock this kernel runs at: stamped inside it (profiling build, tools/kernel_clock.py) and, as a cross-check,
+            # GRBM_GUI_ACTIVE / 8 XCDs / the profiled launch's duration (MI355X_MICROARCH.md, "DVFS give-back")
+            clk = clock_d['layers']['clock_ghz_median'] if clock_d else None
+            clk_grbm = pmc_d.get('clock_ghz_grbm')
+            use_clk = clk or clk_grbm
+            cyc = (n_simd * use_clk * 1e9 / rate) if use_clk else None      # SIMD cycles per VALU instruction issued, as the kernel runs
+            valu = {"bound": "valu_issue", "achieved": rate / 1e9, "unit": "G wave-instructions/s",
+                    "clock_ghz_kernel": clk, "clock_ghz_kernel_grbm": clk_grbm, "clock_ghz_microbench": peak['clock_ghz_microbench'],
+                    "simd_cycles_per_valu_instruction": cyc,
+                    "microbench_cycles_per_instruction": {k: peak[k] for k in ('full_rate', 'mix', 'half_rate')},
+                    "peak": (n_simd * use_clk / peak['mix']) if use_clk else None,
+                    "frac": (peak['mix'] / cyc) if cyc else None,
+                    "frac_of_full_rate_peak": (peak['full_rate'] / cyc) if cyc else None,
                     "valu_instructions_per_launch": pmc['SQ_INSTS_VALU'], "active_lanes_of_64": pmc.get('active_lanes'),
-                    "source": f"SQ_INSTS_VALU of the scoring launch from profiles/{pmc_file} (rocprofv3 --pmc, same command) / its live launch time; "
-                              "peak = 1024 SIMDs x the rate one SIMD retires a kernel-like instruction mix at 6 waves per SIMD "
-                              "(tools/valu_issue_bench.hip, profiles/r02_valu_issue.json; wall-clock based, full-rate ops beside it)"}
+                    "wave_wait_fraction": (pmc['SQ_WAIT_ANY'] / pmc['SQ_WAVE_CYCLES']) if pmc.get('SQ_WAVE_CYCLES') else None,
+                    "source": f"SQ_INSTS_VALU of the scoring launch from profiles/{PROFILE_ROUND}_pmc.json (rocprofv3 --pmc, same command, same build: "
+                              f"build_id {lib_id}) / its live launch time; peak = 1024 SIMDs x the kernel's own clock / the SIMD cycles a wave64 instruction of a "
+                              f"kernel-like mix costs at 6 waves per SIMD (tools/valu_issue_bench.hip, profiles/{PROFILE_ROUND}_valu_issue.json: wall time x in-loop clock)"}
         out = {
             "metric": "rendered+scored candidate poses/sec @%dx%d" % (W, H),
             "value": poses / dt, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -321,7 +334,8 @@ def main():
             # peak.  The kernel keeps a candidate's depth image in LDS, so the bytes that really cross the HBM pins (`traffic`,
             # PMC) are a small fraction of the algorithmic ones and HBM is not what binds it: see measured_hbm_* and valu_issue.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "pmc_stale": bool(stale_t or stale_p or stale_c),
+                         "build_id": lib_id,
                          "measured_hbm_GBs": (traffic / (kern['score'] * 1e-3) / 1e9) if traffic else None,
                          "measured_hbm_frac": (traffic / (kern['score'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "binding_resource": "vector instruction issue (valu_issue below), not HBM",

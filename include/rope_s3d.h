@@ -44,6 +44,10 @@ int rope_create(rope_ctx **out, int device);
 void rope_destroy(rope_ctx *ctx);
 const char *rope_last_error(rope_ctx *ctx);
 
+/* Identity of the sources this library was built from (first 16 hex digits of their SHA-256, rope_s3d_amd/build.py:source_hash):
+ * committed profiles carry the same string, so a benchmark can tell whether their counters belong to the build it is timing. */
+const char *rope_build_id(void);
+
 /* Robot geometry + kinematic chain, uploaded once.
  * Replaces MeshLoader.load + pyrender.Mesh.from_trimesh (render_utils.py:22-41) and
  * klampt.WorldModel(urdf) (kinematics.py:23-33).

@@ -324,6 +324,11 @@ extern "C" void rope_destroy(rope_ctx *c)
     delete c;
 }
 
+#ifndef ROPE_BUILD_ID
+#define ROPE_BUILD_ID "unknown"
+#endif
+extern "C" const char *rope_build_id(void) { return ROPE_BUILD_ID; }
+
 extern "C" const char *rope_last_error(rope_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 // for the host-side stage machine (rope_predict.cpp), which sees the context only through the C ABI
@@ -1501,6 +1506,32 @@ extern "C" int rope_set_strategy(rope_ctx *c, int flags)
 }
 
 #ifdef ROPE_PROFILE
+namespace rope { hipError_t read_clock_stamps(unsigned long long *out); }
+
+// Profiling build: the shader clock (GHz) during the last scoring launch of a large batch — median over its workgroups of
+// delta s_memtime / delta s_memrealtime (100 MHz); ghz[1] = the launch's length by the same stamps in ms (first start to last end)
+extern "C" int rope_debug_clock(rope_ctx *c, double *ghz)
+{
+    if (!c || !ghz) return ROPE_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> st(4 * 1024);
+    HIP_TRY(c, read_clock_stamps(st.data()));
+    std::vector<double> f;
+    unsigned long long r_lo = ~0ull, r_hi = 0;
+    const int n = std::min(1024, 2 * c->n_cu);
+    for (int i = 0; i < n; i++) {
+        const unsigned long long t0 = st[4 * i], r0 = st[4 * i + 1], t1 = st[4 * i + 2], r1 = st[4 * i + 3];
+        if (r1 > r0 + 100 && t1 > t0) f.push_back((double)(t1 - t0) / ((double)(r1 - r0) * 10.0));       // workgroups that ran for more than a microsecond
+        if (r1 > r0) { r_lo = std::min(r_lo, r0); r_hi = std::max(r_hi, r1); }
+    }
+    if (f.empty()) ARG_FAIL(c, "rope_debug_clock: no stamps (run a batch of more than 256 rows first)");
+    std::sort(f.begin(), f.end());
+    ghz[0] = f[f.size() / 2];
+    ghz[1] = (double)(r_hi - r_lo) * 1.0e-5;
+    return ROPE_OK;
+}
+
 extern "C" int rope_debug_skip(rope_ctx *c, int mask)
 {
     if (!c) return ROPE_E_ARG;

@@ -1268,12 +1268,25 @@ raster_score_kernel(FrameParams fp, RobotParams rp, RasterArgs ra)
 // chip (two workgroups per CU) — of the tiles x candidates pairs of a pass about four in five have nothing to do, and a
 // launch over all of them spends a fifth of a millisecond starting workgroups that leave at once.  score_queue_kernel
 // builds the queue.  A workgroup asks for its next pair while it works on the current one.
+#ifdef ROPE_PROFILE
+// Profiling build only: per workgroup of the last raster_queue_kernel<.., MODE_SCORE> launch, s_memtime (shader cycles) and
+// s_memrealtime (constant 100 MHz) at its start and end — the clock the chip held during THIS kernel (rope_debug_clock;
+// MI355X_MICROARCH.md "DVFS give-back" item 6).  A buffer of its own: nothing else reads it.
+__device__ unsigned long long g_clock_stamps[4 * 1024];
+#endif
+
 template <int LOSS, int MODE, bool CLIP>
 __global__ void __launch_bounds__(NTHREADS, CLIP ? ROPE_MIN_WAVES_CLIP : ((LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? ROPE_MIN_WAVES_FULL : ROPE_MIN_WAVES_PER_SIMD))
 raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_t *__restrict__ items, size_t segment,
                     int *__restrict__ counters /* [1] next ticket, [2 + k] pairs queued in class k */)
 {
     __shared__ int s_item;
+#ifdef ROPE_PROFILE
+    if (MODE == MODE_SCORE && threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_clock_stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+        g_clock_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (threadIdx.x == 0) s_item = atomicAdd(&counters[1], 1);
     __syncthreads();
     // the queue is QUEUE_CLASSES segments of `segment` entries, heaviest pairs first (score_queue_kernel): ticket -> (class, place)
@@ -1296,7 +1309,20 @@ raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_
         if (threadIdx.x == 0) s_item = next;
         __syncthreads();
     }
+#ifdef ROPE_PROFILE
+    if (MODE == MODE_SCORE && threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_clock_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        g_clock_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
+
+#ifdef ROPE_PROFILE
+hipError_t read_clock_stamps(unsigned long long *out /* 4 x 1024 */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_stamps), sizeof(g_clock_stamps));
+}
+#endif
 
 // The queue of raster_queue_kernel: 32 threads per (candidate, word of its tile masks), eight candidates per workgroup.
 // Pairs whose tile the candidate's own links reach (or, without shared layers, any of its links) are queued — one atomic

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
     'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
     'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
-    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free')
+    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free', 'rope_build_id')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP, STAGE_TSWEEP = 0, 1, 2, 3, 4
@@ -114,6 +114,7 @@ def load_library(path: str = None):
     lib.rope_set_strategy.argtypes = [vp, i32]
     if hasattr(lib, 'rope_debug_skip'):                 # librope_hip_profile.so only (ROPE_HIP_LIB=...)
         lib.rope_debug_skip.argtypes = [vp, i32]
+        lib.rope_debug_clock.argtypes = [vp, vp]
     lib.rope_predict.argtypes = [vp, C.POINTER(PredictArgs), vp, vp, C.POINTER(C.c_int64)]
     lib.rope_set_robot_mesh.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     lib.rope_partition_mesh.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
@@ -129,6 +130,8 @@ def load_library(path: str = None):
     lib.rope_eval_targets.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.rope_lookup_score_targets.argtypes = [vp, vp, vp, vp]
     lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
+    lib.rope_build_id.argtypes = []
+    lib.rope_build_id.restype = C.c_char_p
     lib.rope_host_alloc.argtypes = [C.c_size_t]
     lib.rope_host_alloc.restype = C.c_void_p
     lib.rope_host_free.argtypes = [vp]
@@ -160,6 +163,11 @@ def pack_target(depth: np.ndarray, mask_bits: np.ndarray = None) -> np.ndarray:
     if mask_bits is not None:
         q |= np.asarray(mask_bits, np.uint64) << np.uint64(40)
     return np.ascontiguousarray(q)
+
+
+def build_id() -> str:
+    """rope_build_id of the loaded library: the hash of the sources it was built from."""
+    return load_library().rope_build_id().decode()
 
 
 def pinned_empty(shape, dtype) -> np.ndarray:
@@ -476,6 +484,15 @@ class Engine:
         if not hasattr(self._lib, 'rope_debug_skip'):
             raise EngineError("rope_debug_skip: not in this library; build librope_hip_profile.so and point ROPE_HIP_LIB at it")
         self._check(self._lib.rope_debug_skip(self._ctx, int(mask)), 'rope_debug_skip')
+
+    def debug_clock(self):
+        """Profiling build only: (shader clock in GHz during the last scoring launch of a large batch, that launch's length in ms),
+        from s_memtime / s_memrealtime stamps of its workgroups."""
+        if not hasattr(self._lib, 'rope_debug_clock'):
+            raise EngineError("rope_debug_clock: not in this library; build librope_hip_profile.so and point ROPE_HIP_LIB at it")
+        out = np.zeros(2)
+        self._check(self._lib.rope_debug_clock(self._ctx, _p(out)), 'rope_debug_clock')
+        return float(out[0]), float(out[1])
 
     def profile_eval(self, n_render: int, loss: int, crop=None, reps: int = 10):
         """-> dict of average milliseconds per pass (HIP events on the engine stream): fk (+bounds), layer (shared

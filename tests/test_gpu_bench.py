@@ -30,6 +30,13 @@ def test_bench_line_single_gpu():
     assert abs(r['achieved'] - r['bytes_per_candidate'] * 4096 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
     assert d['unshared_value'] < d['value'] * 1.05                     # drawing six links per candidate is never the faster layout
     assert d['cpu_baseline']['gpu_errors_vs_port']['identical_bits'] is True and d['cpu_baseline']['kind'] == 'port'
+    # the committed counters belong to this build (tools/summarize_prof.py stamps them with the hash of the sources): a kernel
+    # edit without a new profile would make bench.py drop them and say so
+    from rope_s3d_amd import build, engine
+    assert r['build_id'] == build.source_hash() == engine.build_id()
+    assert r['pmc_stale'] is False, "profiles/ were taken on another build: run tools/rocprof_bench.sh + tools/summarize_prof.py again"
+    assert r['traffic'] and r['valu_issue'] and 0.2 < r['valu_issue']['frac'] < 1.2
+    assert 1.0 < r['valu_issue']['clock_ghz_kernel_grbm'] < 2.6
 
 
 def test_bench_starts_two_ranks_itself():

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""The shader clock the chip holds DURING the scoring launch of the bench workload (profiling build: s_memtime / s_memrealtime
+stamps of every workgroup of raster_queue_kernel<DEPTH,SCORE>), after two seconds of back-to-back passes.
+
+    python tools/build_variants.py profile
+    ROPE_HIP_LIB=$PWD/rope_s3d_amd/csrc/librope_hip_profile.so python tools/kernel_clock.py > gpurun_out/r03/kernel_clock.json
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
+from bench import slu_grid
+from rope_s3d_amd import engine as eng
+from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
+from rope_s3d_amd.projection import Intrinsics, view_matrix
+from rope_s3d_amd.robot import RobotModel
+
+robot = RobotModel.from_urdf()
+intr = Intrinsics('640_480_color')
+PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+e = eng.Engine(0)
+e.set_robot(robot)
+e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+q = np.random.default_rng(7919).uniform(robot.joint_limits[:, 0], robot.joint_limits[:, 1]) * np.array([1, 1, 1, 0, 0, 0])
+depth, ids = e.render(q, 6)
+e.set_target(eng.pack_target(depth.astype(np.float64), None), None, np.zeros(8, np.uint8))
+e.upload_candidates(slu_grid(robot.joint_limits, 16))
+out = {}
+for name, flag in (('layers', 0), ('unshared', e.NO_LAYERS)):
+    e.set_strategy(flag)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:                   # the governor settles under this load
+        for _ in range(20):
+            e.eval_resident(6, eng.LOSS_DEPTH)
+        e.sync()
+    samples = []
+    for _ in range(15):
+        e.eval_resident(6, eng.LOSS_DEPTH)
+        e.sync()
+        samples.append(e.debug_clock())
+    ghz = sorted(s[0] for s in samples)
+    out[name] = {'clock_ghz_median': ghz[len(ghz) // 2], 'clock_ghz_min': ghz[0], 'clock_ghz_max': ghz[-1],
+                 'launch_ms_by_stamps_median': sorted(s[1] for s in samples)[len(samples) // 2]}
+e.set_strategy(0)
+from rope_s3d_amd.build import source_hash
+print(json.dumps({'build_id': source_hash(), 'kernel': 'raster_queue_kernel<DEPTH,SCORE>, bench workload (4096 candidates, 640x480), profiling build with stamps',
+                  'method': 'median over workgroups of delta s_memtime / delta s_memrealtime x 100 MHz, after 2 s of back-to-back passes',
+                  **out}, indent=1))
