@@ -183,7 +183,7 @@ def main():
 
     from rope_s3d_amd import engine as eng
     from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
-    from rope_s3d_amd.projection import Intrinsics, view_matrix
+    from rope_s3d_amd.projection import Intrinsics, camera_matrix
     from rope_s3d_amd.robot import RobotModel
 
     from rope_s3d_amd.urdf import URDFReader
@@ -200,7 +200,7 @@ def main():
         label = "configs[1]: mh5l_limited URDF, 640x480, %d candidates/frame (%d^3 SLU grid), depth-only loss, 6 links, one frame per rank"
         args.grid = args.grid or 16
     W, H = intr.width, intr.height
-    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(cam_pose)
+    PV = camera_matrix(cam_pose, intr, ZNEAR, ZFAR)
 
     e = eng.Engine(device)
     e.set_robot(robot)

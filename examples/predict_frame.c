@@ -1,16 +1,26 @@
 /*
- * predict_frame.c — a host that is not Python: one frame through the whole prediction path using nothing but the C ABI
- * of librope_hip.so (include/rope_s3d.h).
+ * predict_frame.c — a host that is not Python: one RGB-D frame through the whole prediction path using nothing but the C ABI
+ * of librope_hip.so (include/rope_s3d.h), starting where the reference's Predictor starts: the robot's meshes and joint chain,
+ * a camera pose, the camera's intrinsics, and the frame as the camera delivers it.
  *
  *     gcc -O2 -Iinclude examples/predict_frame.c -Lrope_s3d_amd/csrc -lrope_hip \
  *         -Wl,-rpath,$PWD/rope_s3d_amd/csrc -Wl,-rpath-link,/opt/rocm/lib -lm -o predict_frame
  *     ./predict_frame <bundle directory>        # prints the six joint angles, %.17g
  *
- * The bundle is a directory of raw little-endian arrays (tools/dump_frame_bundle.py writes one): the welded link
- * meshes and the joint chain (what URDFReader + MeshLoader give the reference), the camera, one prepared target
- * frame, the lookup pose grid and its crop.  Calls, in order: rope_create, rope_set_robot_mesh, rope_set_camera,
- * rope_set_target, rope_lookup_build, rope_predict — the reference's Predictor.__init__ + Predictor.run
- * (robotpose/prediction/predict.py:38-124,127-375) with the 'SLU' stage list of stages.py:152-168.
+ * The bundle is a directory of raw little-endian arrays (tools/dump_frame_bundle.py writes one) — INPUTS only: the welded link
+ * meshes and the joint chain (what URDFReader + MeshLoader give the reference), the joint limits, the camera pose, the base
+ * intrinsics and the down-sampling factor, the colour-coded frame and its depth, the links' colours, the lookup grid's
+ * divisions.  No matrix, crop, grid or packed target comes from Python: this program derives them through the library.
+ *
+ *   Predictor.__init__ (robotpose/prediction/predict.py:38-124)
+ *     Intrinsics.downscale + the string round trip of Renderer's constructor (projection.py:127-136,20-46; render.py:41)    here
+ *     Renderer.setCameraPose + IntrinsicsCamera (render.py:107-111, projection.py:161-169)        rope_camera_matrix, rope_set_camera
+ *     MeshLoader / Klampt world (render_utils.py:22-41, kinematics.py:23-33)                    rope_set_robot_mesh
+ *     Crop (crop.py:50-146)                          rope_crop_divisions + rope_lookup_grid + rope_coverage, box of the covered pixels
+ *     RobotLookupManager.get + the depth table (lookup.py:39-106,184-283)                      rope_lookup_grid, rope_lookup_build
+ *   Predictor.run (predict.py:127-375)
+ *     _downsample + _loadSynthetic + _load_target (predict.py:378-381,445-469,397-413)          rope_prepare_synthetic, rope_set_target
+ *     the 'SLU' stage list (stages.py:152-168)                                                  rope_predict
  */
 #include <math.h>
 #include <stdint.h>
@@ -46,6 +56,15 @@ static rope_stage stage(int kind, int to_render, int count, unsigned joints, dou
     return s;
 }
 
+/* The reference's Renderer rebuilds the Predictor's down-scaled Intrinsics from their printed form (render.py:41,
+ * projection.py:20-46,183-184): librealsense prints six significant digits, so that is what the renderer sees. */
+static double as_printed(double x)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%g", x);
+    return strtod(buf, NULL);
+}
+
 #define CHECK(call)                                                                          \
     do {                                                                                     \
         int rc_ = (call);                                                                    \
@@ -56,27 +75,69 @@ int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: %s <bundle directory>\n", argv[0]); return 2; }
     const char *dir = argv[1];
-    size_t n_vo, n_grid, n_px;
+    size_t n_vo, n_color, n_depth;
     float *verts = load(dir, "verts.f32", 4, NULL);
     int32_t *faces = load(dir, "faces.i32", 4, NULL);
     int32_t *vtx_off = load(dir, "vtx_off.i32", 4, &n_vo), *tri_off = load(dir, "tri_off.i32", 4, NULL);
     double *joint_fixed = load(dir, "joint_fixed.f64", 8, NULL), *joint_axes = load(dir, "joint_axes.f64", 8, NULL);
-    double *PV = load(dir, "PV.f64", 8, NULL), *clip = load(dir, "clip.f64", 8, NULL);
-    int32_t *dims = load(dir, "dims.i32", 4, NULL);                  /* W, H */
     double *limits = load(dir, "limits.f64", 8, NULL), *camera_pose = load(dir, "camera_pose.f64", 8, NULL);
-    uint64_t *tq = load(dir, "tq.u64", 8, &n_px);
-    float *t32 = load(dir, "t32.f32", 4, NULL);
-    uint8_t *flags = load(dir, "flags.u8", 1, NULL);
-    double *grid = load(dir, "grid.f64", 8, &n_grid);
-    int32_t *crop = load(dir, "crop.i32", 4, NULL);
-    if (n_px != (size_t)dims[0] * dims[1]) { fprintf(stderr, "target plane does not match %dx%d\n", dims[0], dims[1]); return 2; }
-
+    double *intr = load(dir, "intrinsics.f64", 8, NULL);            /* W0, H0, ppx, ppy, fx, fy of the camera's full-size image */
+    int32_t *setup = load(dir, "setup.i32", 4, NULL);               /* down-sampling factor, lookup divisions per S/L/U joint */
+    int32_t *link_blue = load(dir, "link_blue.i32", 4, NULL);       /* channel 0 of each of the six rendered links' colours */
+    uint8_t *color = load(dir, "color.u8", 1, &n_color);
+    float *depth = load(dir, "depth.f32", 4, &n_depth);
+    const int W0 = (int)intr[0], H0 = (int)intr[1], ds = setup[0], div = setup[1];
+    const double znear = 0.05, zfar = 100.0;                        /* pyrender's IntrinsicsCamera defaults (projection.py:161-169) */
+    if (ds < 1 || W0 % ds || H0 % ds || n_depth != (size_t)W0 * H0 || n_color != 3 * n_depth) {
+        fprintf(stderr, "frame does not match %dx%d / %d\n", W0, H0, ds);
+        return 2;
+    }
+    const int W = W0 / ds, H = H0 / ds;
+    const double cx = as_printed(intr[2] / ds), cy = as_printed(intr[3] / ds), fx = as_printed(intr[4] / ds), fy = as_printed(intr[5] / ds);
+    double PV[16];
     rope_ctx *ctx = NULL;
+    if (rope_camera_matrix(camera_pose, fx, fy, cx, cy, W, H, znear, zfar, PV)) { fprintf(stderr, "rope_camera_matrix: bad camera\n"); return 2; }
+
     CHECK(rope_create(&ctx, 0));
     CHECK(rope_set_robot_mesh(ctx, verts, faces, vtx_off, tri_off, (int)n_vo - 1, joint_fixed, joint_axes));
-    CHECK(rope_set_camera(ctx, PV, dims[0], dims[1], clip[0], clip[1]));
-    CHECK(rope_lookup_build(ctx, grid, (int)(n_grid / 6), 6, crop));           /* once per camera pose */
-    CHECK(rope_set_target(ctx, tq, t32, flags));                             /* once per frame */
+    CHECK(rope_set_camera(ctx, PV, W, H, znear, zfar));
+
+    /* Crop of the six rendered links: the box of every pixel any pose of the crop grid covers, padded by 10 (crop.py:98-112) */
+    int32_t cdiv[6], crop[4];
+    if (rope_crop_divisions((int64_t)W * H, 6, cdiv)) { fprintf(stderr, "rope_crop_divisions failed\n"); return 1; }
+    const int64_t n_crop = rope_lookup_grid(limits, cdiv, NULL, 0);
+    double *crop_grid = malloc((size_t)n_crop * 6 * sizeof(double));
+    uint8_t *cover = malloc((size_t)W * H), *any = calloc((size_t)W * H, 1);
+    if (!crop_grid || !cover || !any || rope_lookup_grid(limits, cdiv, crop_grid, n_crop) != n_crop) { fprintf(stderr, "crop grid failed\n"); return 1; }
+    for (int64_t lo = 0; lo < n_crop; lo += 32768) {
+        const int n = (int)(n_crop - lo < 32768 ? n_crop - lo : 32768);
+        CHECK(rope_coverage(ctx, crop_grid + 6 * lo, n, 6, cover));
+        for (size_t i = 0; i < (size_t)W * H; i++) any[i] |= cover[i];
+    }
+    int r0 = H, r1 = -1, c0 = W, c1 = -1;
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++)
+            if (any[(size_t)r * W + c]) { if (r < r0) r0 = r; if (r > r1) r1 = r; if (c < c0) c0 = c; if (c > c1) c1 = c; }
+    if (r1 < 0) { fprintf(stderr, "the robot is not in view\n"); return 1; }
+    crop[0] = r0 - 10 > 0 ? r0 - 10 : 0; crop[1] = r1 + 10 < H - 1 ? r1 + 10 : H - 1;
+    crop[2] = c0 - 10 > 0 ? c0 - 10 : 0; crop[3] = c1 + 10 < W - 1 ? c1 + 10 : W - 1;
+
+    /* Lookup grid over S, L, U and its table of cropped depth images, once per camera pose (lookup.py:39-106) */
+    const int32_t ldiv[6] = {div, div, div, 0, 0, 0};
+    const int64_t n_grid = rope_lookup_grid(limits, ldiv, NULL, 0);
+    double *grid = malloc((size_t)n_grid * 6 * sizeof(double));
+    if (!grid || rope_lookup_grid(limits, ldiv, grid, n_grid) != n_grid) { fprintf(stderr, "lookup grid failed\n"); return 1; }
+    CHECK(rope_lookup_build(ctx, grid, (int)n_grid, 6, crop));
+
+    /* The frame: down-sampled, link masks read off the colour render, packed (once per frame) */
+    uint64_t *tq = malloc((size_t)W * H * sizeof(uint64_t));
+    float *t32 = malloc((size_t)W * H * sizeof(float));
+    uint8_t flags[8];
+    if (!tq || !t32 || rope_prepare_synthetic(color, (int64_t)3 * W0, depth, 1, (int64_t)4 * W0, H0, W0, ds, link_blue, 6, 6, tq, t32, NULL, flags)) {
+        fprintf(stderr, "rope_prepare_synthetic failed\n");
+        return 1;
+    }
+    CHECK(rope_set_target(ctx, tq, t32, flags));
 
     enum { S = 1, L = 2, U = 4 };
     rope_stage stages[9];
@@ -97,12 +158,13 @@ int main(int argc, char **argv)
     memset(&a, 0, sizeof a);
     a.stages = stages; a.n_stages = 9; a.speculate = 3;
     a.limits = limits; a.camera_pose = camera_pose; a.min_ang_inc = min_ang_inc;
-    a.lookup_angles = grid; a.n_lookup = (int)(n_grid / 6); a.use_table = 1; a.lookup_crop = crop;
+    a.lookup_angles = grid; a.n_lookup = (int)n_grid; a.use_table = 1; a.lookup_crop = crop;
     double angles[6];
     int64_t evals = 0;
     CHECK(rope_predict(ctx, &a, angles, NULL, &evals));
     for (int j = 0; j < 6; j++) printf("%.17g%c", angles[j], j == 5 ? '\n' : ' ');
-    fprintf(stderr, "%lld candidate poses rendered and scored\n", (long long)evals);
+    fprintf(stderr, "crop %d %d %d %d, %lld lookup poses, %lld candidate poses rendered and scored\n", crop[0], crop[1], crop[2], crop[3],
+            (long long)n_grid, (long long)evals);
     rope_destroy(ctx);
     return 0;
 }

@@ -78,6 +78,24 @@ int rope_set_robot_mesh(rope_ctx *ctx, const float *verts, const int32_t *faces,
 int rope_partition_mesh(const float *verts, int n_verts, const int32_t *faces, int n_tris, int max_tris, int max_verts,
                         int32_t *tri_order, int32_t *meshlet_first);
 
+/* Host only (no context): camera pose + pinhole intrinsics -> the matrix P·V rope_set_camera takes (16 doubles, row-major).
+ * Replaces Renderer.setCameraPose's pose convention (render.py:107-111: roll = a4 + pi/2, pitch = a3, yaw = a5; makePose /
+ * angToPoseArr, render_utils.py:56-108: R = Rz(yaw)·Ry(pitch)·Rx(roll), camera looking along -Z with +Y up, V = pose^-1) and
+ * Intrinsics.pyrender_camera (projection.py:161-169: pyrender 0.1.45's IntrinsicsCamera projection).
+ *   pose  [x, y, z, a3, a4, a5]: position in metres, the three angles in radians, as the reference's camera_pose arrays */
+int rope_camera_matrix(const double *pose, double fx, double fy, double cx, double cy, int W, int H, double znear, double zfar, double *PV);
+
+/* Host only (no context): the Lookup stage's pose grid (RobotLookupCreator / RobotLookupManager, lookup.py:39-66): divisions[j] >= 1
+ * samples of joint j between its limits (6 x 2 doubles), np.linspace's values, joint 0 varying fastest; divisions[j] <= 0: joint j
+ * is not part of the grid (angle 0).  Returns the number of rows; writes rows x 6 doubles to `out` when it is not NULL and
+ * `capacity` rows fit (else ROPE_E_ARG). */
+int64_t rope_lookup_grid(const double *limits, const int32_t *divisions, double *out, int64_t capacity);
+
+/* Host only (no context): the divisions (rope_lookup_grid's convention) of the pose grid Crop renders to find the image bounds of the
+ * first num_links links (2..6) of the robot at an image of n_pixels pixels (robotpose/crop.py:114-146; constants.py:19-23).  With
+ * rope_lookup_grid and rope_coverage this replaces Crop._create (crop.py:50-96): bounds = box of the covered pixels, padded by 10. */
+int rope_crop_divisions(int64_t n_pixels, int num_links, int32_t *divisions);
+
 /* Camera: PV = P·V (4x4 row-major doubles), image size and clip planes.
  * Replaces Renderer.setCameraPose (render.py:107-111) + Intrinsics.pyrender_camera
  * (projection.py:161-169) + pyrender.OffscreenRenderer(W,H) (render.py:60). */

@@ -1,6 +1,7 @@
 // rope_abi.hip — host side of librope_hip.so: context, HBM buffers, launch sequencing.
 // Declarations and the reference call sites each entry point replaces: include/rope_s3d.h.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -174,6 +175,36 @@ struct rope_ctx {
     uint32_t *d_key = nullptr;
     float *d_depth = nullptr;
     uint8_t *d_ids = nullptr, *d_cover = nullptr;
+};
+
+// ---- roctx ranges (the reference times its stages with utils.Timer / FancyTimer, robotpose/utils.py:122-180).
+// Named ranges around the phases of a pass and around every stage of the stage machine show up in `rocprofv3 --marker-trace`;
+// the library is looked up at run time (librocprofiler-sdk-roctx, else the older libroctx64) and its absence costs two null checks.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (const char *e = std::getenv("ROPE_ROCTX")) if (e[0] == '0') return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+}  // namespace
+
+void rope_range_push(const char *name) { if (roctx().push) (void)roctx().push(name); }      // also used by rope_predict.cpp (per stage)
+void rope_range_pop() { if (roctx().pop) (void)roctx().pop(); }
+struct RopeRange {
+    explicit RopeRange(const char *name) { rope_range_push(name); }
+    ~RopeRange() { rope_range_pop(); }
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -623,6 +654,116 @@ extern "C" int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride
     return ROPE_OK;
 }
 
+// Host only: camera pose + pinhole intrinsics -> P·V, the matrix rope_set_camera takes.  Every step is one IEEE double operation in
+// the written order (the library is built with -ffp-contract=off), sin / cos from libm.
+//   pose   [x, y, z, a3, a4, a5] as Renderer.setCameraPose takes it (render.py:107-111): roll = a4 + pi/2, pitch = a3, yaw = a5,
+//          camera-to-world R = Rz(yaw)·Ry(pitch)·Rx(roll) by the element formulas of angToPoseArr (render_utils.py:56-85),
+//          t = (x, y, z); the camera looks along its -Z, +Y up (OpenGL); V = the rigid inverse [R^T | -R^T t]
+//   P      pyrender 0.1.45's IntrinsicsCamera.get_projection_matrix (projection.py:161-169): P00 = 2fx/W, P11 = 2fy/H,
+//          P02 = 1 - 2cx/W, P12 = 2cy/H - 1, P22 = (f+n)/(n-f), P23 = 2fn/(n-f), P32 = -1
+extern "C" int rope_camera_matrix(const double *pose, double fx, double fy, double cx, double cy, int W, int H, double znear, double zfar,
+                                  double *PV)
+{
+    if (!pose || !PV || W < 1 || H < 1 || !(znear > 0.0) || !(zfar > znear)) return ROPE_E_ARG;
+    const double yaw = pose[5], pitch = pose[3], roll = pose[4] + 3.141592653589793 / 2;
+    const double c0 = std::cos(yaw), c1 = std::cos(pitch), c2 = std::cos(roll), s0 = std::sin(yaw), s1 = std::sin(pitch), s2 = std::sin(roll);
+    double R[3][3];
+    R[0][0] = c0 * c1;
+    R[1][0] = c1 * s0;
+    R[2][0] = -1 * s1;
+    R[0][1] = c0 * s1 * s2 - c2 * s0;
+    R[1][1] = c0 * c2 + (s0 * s1) * s2;
+    R[2][1] = c1 * s2;
+    R[0][2] = s0 * s2 + c0 * c2 * s1;
+    R[1][2] = c2 * s0 * s1 - c0 * s2;
+    R[2][2] = c1 * c2;
+    double V[4][4] = {};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) V[i][j] = R[j][i];
+        V[i][3] = -((R[0][i] * pose[0] + R[1][i] * pose[1]) + R[2][i] * pose[2]);
+    }
+    V[3][3] = 1.0;
+    const double w = (double)W, h = (double)H;
+    const double P00 = 2.0 * fx / w, P11 = 2.0 * fy / h, P02 = 1.0 - 2.0 * cx / w, P12 = 2.0 * cy / h - 1.0;
+    const double P22 = (zfar + znear) / (znear - zfar), P23 = (2.0 * zfar * znear) / (znear - zfar);
+    for (int j = 0; j < 4; j++) {
+        PV[j] = P00 * V[0][j] + P02 * V[2][j];
+        PV[4 + j] = P11 * V[1][j] + P12 * V[2][j];
+        PV[8 + j] = P22 * V[2][j] + P23 * V[3][j];
+        PV[12 + j] = -V[2][j];
+    }
+    for (int k = 0; k < 16; k++)
+        if (!std::isfinite(PV[k])) return ROPE_E_ARG;
+    return ROPE_OK;
+}
+
+// Host only: the Lookup stage's pose grid in the reference's order (lookup.py:39-66).  divisions[j] >= 1: joint j takes that many
+// samples between its limits (np.linspace: lo + i * step, the last one hi itself; a single sample is lo), clipped to
+// LOOKUP_MAX_DIV_PER_LINK = 200 (constants.py:30); divisions[j] <= 0: joint j is not part of the grid and stays 0.  Joint 0 varies
+// fastest.  Returns the number of rows (the product of the sample counts); writes them when `out` is given and `capacity` rows fit
+// (ROPE_E_ARG otherwise).
+extern "C" int64_t rope_lookup_grid(const double *limits, const int32_t *divisions, double *out, int64_t capacity)
+{
+    if (!limits || !divisions) return ROPE_E_ARG;
+    int64_t div[6], n = 1;
+    for (int j = 0; j < 6; j++) {
+        div[j] = divisions[j] < 1 ? 1 : (divisions[j] > 200 ? 200 : divisions[j]);
+        n *= div[j];
+    }
+    if (!out) return n;
+    if (capacity < n) return ROPE_E_ARG;
+    int64_t repeat = 1;
+    for (int j = 0; j < 6; j++) {
+        const double lo = limits[2 * j], hi = limits[2 * j + 1], dv = (double)(div[j] - 1), delta = hi - lo;
+        const double step = div[j] > 1 ? delta / dv : 0.0;
+        for (int64_t r = 0; r < n; r++) {
+            const int64_t i = (r / repeat) % div[j];
+            double v = 0.0;                                         // not part of the grid: np.zeros
+            if (divisions[j] >= 1) {
+                if (div[j] == 1) v = lo;
+                else if (i == div[j] - 1) v = hi;
+                else v = step == 0.0 ? ((double)i / dv) * delta + lo : (double)i * step + lo;
+            }
+            out[6 * r + j] = v;
+        }
+        repeat *= div[j];
+    }
+    return n;
+}
+
+// Host only: the divisions of the pose grid Crop renders to find the image bounds of the first `num_links` links
+// (robotpose/crop.py:114-146), in rope_lookup_grid's convention — feed them to rope_lookup_grid for the poses.  Weights 6:3:3:0:1
+// over the joints S L U R B (constants.py:19: CROP_RENDER_WEIGHTING), a budget of 20 s at the reference's cost model of
+// pixels x 1.2e-8 + 0.002 s per render (crop.py:121-123), at most 50 samples per joint; joints beyond the rendered links sit at
+// their lower limit (np.linspace(lo, hi, 1)), R and T are not part of the grid (CROP_VARYING = 'SLUB') and stay 0.
+extern "C" int rope_crop_divisions(int64_t n_pixels, int num_links, int32_t *divisions)
+{
+    if (!divisions || n_pixels < 1 || num_links < 2 || num_links > 6) return ROPE_E_ARG;
+    const double weighting[6] = {6, 3, 3, 0, 1, 0};
+    const int n = num_links - 1;
+    double w[6], sum = 0.0, prod = 1.0;
+    int nz = 0;
+    for (int j = 0; j < n; j++) sum += weighting[j];
+    for (int j = 0; j < n; j++) {
+        w[j] = weighting[j] / sum;
+        if (w[j] != 0.0) { prod *= w[j]; nz++; }
+    }
+    const double num_poses = 20.0 / ((double)n_pixels * 1.2 * 1.0e-8 + .002);
+    const double scale = std::pow(num_poses / prod, 1.0 / (double)nz);
+    const bool varying[6] = {true, true, true, false, true, false};          // S L U B
+    for (int j = 0; j < 6; j++) {
+        int d = 1;
+        if (j < n) {
+            double b = w[j] * scale;
+            if (b < 1.0) b = 1.0;
+            if (b > 50.0) b = 50.0;
+            d = (int)b;
+        }
+        divisions[j] = varying[j] ? d : 0;
+    }
+    return ROPE_OK;
+}
+
 // Can a vertex of the robot get behind the near plane of camera PV (P·V, row-major doubles)?  z + w is affine in the world
 // position; over the ball of radius `reach` about the base origin it is at least its value at the origin minus |gradient|
 // times the radius.  Conservative with a centimetre to spare: "no" means the kernels without the clipping code draw every
@@ -933,7 +1074,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     // And on frames of a few tiles only (the Predictor's 160x90 is two): on a 25-tile frame two thirds of the workgroups belong to tiles
     // the robot does not reach — the masks of the separate launch let them leave at once, here each would do the matrices first.
     const bool geo = split > 1 && !views && c->C <= c->geo_rows && c->n_tiles <= 4 && !(c->strategy & STRATEGY_SEPARATE_GEOMETRY);
-    if (!geo) { int rc = enqueue_geometry(c, n_render, n_shared, fp, views); if (rc) return rc; }
+    if (!geo) { RopeRange r("rope:fk+bounds"); int rc = enqueue_geometry(c, n_render, n_shared, fp, views); if (rc) return rc; }
     c->mvp_valid = !geo;
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     RasterArgs a = base_args(c, n_render);
@@ -971,26 +1112,30 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
         RasterArgs la = a;
         la.layer_sums = c->d_layer_sums; la.tq = c->d_tq; la.t32 = t32_plane(c, loss);
         if (targets) { la.tq = c->d_ftq; la.t32 = tg_t32; la.frame_of = c->frame_of_dev; }
-        { int rc = enqueue_layers(c, la, loss, n_shared, fp); if (rc) return rc; }
+        { RopeRange r("rope:shared-layers"); int rc = enqueue_layers(c, la, loss, n_shared, fp); if (rc) return rc; }
         a.l_begin = n_shared; a.layer_of = c->d_layer_of; a.layer_rep = c->d_layer_rep; a.layers = c->d_layers; a.layer_sums = c->d_layer_sums;
     }
     a.tq = c->d_tq; a.t32 = t32_plane(c, loss); a.sums = c->d_sums;
     if (targets) { a.tq = c->d_ftq; a.t32 = tg_t32; a.frame_of = c->frame_of_dev; }
     if (views) { a.tq = c->d_ftq; a.t32 = c->frames_t32 ? c->d_ft32 : nullptr; a.tl = c->frames_tl ? c->d_ftl : nullptr; a.frame_of = c->dv_frame_of; }
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-    if (split > 1) {
-        int slices = 1;
-        while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->score_target) slices *= 2;
-        HIP_TRY(c, launch_score_gtile(loss, c->C, slices, c->stream, fp, a));
-        c->gtile_dirty = ROPE_SKIP(fp, ~0);
-    } else if (c->C > 256 && !(c->strategy & STRATEGY_NO_QUEUE)) {
-        // fk_mvp_kernel ran (C > 256) and cleared the queue counters; two 12-wave workgroups fit a CU
-        HIP_TRY(c, launch_raster_queue(loss, c->C, 2 * c->n_cu, c->stream, fp, c->rp, a, c->d_qitems, queue_weights(c) ? c->q_segment : 0, c->d_qctr, queue_weights(c),
-                                       use_clip(c, views)));
-    } else {
-        HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a, use_clip(c, views)));
+    {
+        RopeRange r("rope:raster+score");
+        if (split > 1) {
+            int slices = 1;
+            while (slices < 8 && c->C * c->n_tiles * slices * 2 <= c->score_target) slices *= 2;
+            HIP_TRY(c, launch_score_gtile(loss, c->C, slices, c->stream, fp, a));
+            c->gtile_dirty = ROPE_SKIP(fp, ~0);
+        } else if (c->C > 256 && !(c->strategy & STRATEGY_NO_QUEUE)) {
+            // fk_mvp_kernel ran (C > 256) and cleared the queue counters; two 12-wave workgroups fit a CU
+            HIP_TRY(c, launch_raster_queue(loss, c->C, 2 * c->n_cu, c->stream, fp, c->rp, a, c->d_qitems, queue_weights(c) ? c->q_segment : 0, c->d_qctr, queue_weights(c),
+                                           use_clip(c, views)));
+        } else {
+            HIP_TRY(c, launch_raster(MODE_SCORE, loss, c->C, c->stream, fp, c->rp, a, use_clip(c, views)));
+        }
     }
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+    RopeRange fin("rope:finalize");
     if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
     c->err_on_host = c->C <= rope_ctx::HOST_ERR_ROWS;
     if (targets)                                   // every row against its own frame's totals and link flags; no argmin (rows of many frames)
@@ -1506,7 +1651,20 @@ extern "C" int rope_set_strategy(rope_ctx *c, int flags)
 }
 
 #ifdef ROPE_PROFILE
-namespace rope { hipError_t read_clock_stamps(unsigned long long *out); }
+namespace rope { hipError_t read_clock_stamps(unsigned long long *out); hipError_t read_bounds_violations(unsigned int *out); }
+
+// Profiling build: how many indices into the raster kernels' shared arrays / queue segments were out of range since the library
+// was loaded (ROPE_CHECK_INDEX in rope_kernels.hip)
+extern "C" int rope_debug_bounds(rope_ctx *c, int *violations)
+{
+    if (!c || !violations) return ROPE_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned int v = 0;
+    HIP_TRY(c, read_bounds_violations(&v));
+    *violations = (int)v;
+    return ROPE_OK;
+}
 
 // Profiling build: the shader clock (GHz) during the last scoring launch of a large batch — median over its workgroups of
 // delta s_memtime / delta s_memrealtime (100 MHz); ghz[1] = the launch's length by the same stamps in ms (first start to last end)

@@ -388,6 +388,16 @@ __global__ void total_tiles_kernel(const uint64_t *__restrict__ empty_sums, int 
 }
 
 // ------------------------------------------------------------------ raster -----
+// Profiling build only (-DROPE_PROFILE): run-time checks of the indices into the raster kernel's shared arrays and queue segments;
+// violations are counted (rope_debug_bounds) instead of trusted.  The shipped library has none of this code.
+#ifdef ROPE_PROFILE
+__device__ unsigned int g_bounds_violations;
+#define ROPE_CHECK_INDEX(idx, limit) do { if ((long long)(idx) < 0 || (long long)(idx) >= (long long)(limit)) atomicAdd(&g_bounds_violations, 1u); } while (0)
+hipError_t read_bounds_violations(unsigned int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds_violations), sizeof(unsigned int)); }
+#else
+#define ROPE_CHECK_INDEX(idx, limit) do { } while (0)
+#endif
+
 // number of set bits of `m` below this lane (v_mbcnt: no lane-mask registers to keep alive)
 __device__ static inline int bits_below_lane(unsigned long long m)
 {
@@ -918,6 +928,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
             const int bx0 = b.x & 0x1FFF;
             if (bx0 <= b.y && bx0 <= wx1 && b.y >= wx0 && b.z <= wy1 && b.w >= wy0) {
                 int pos = atomicAdd(&s_count, 1);
+                ROPE_CHECK_INDEX(pos, MAX_MESHLETS);
                 s_list[pos] = (uint16_t)(m | ((b.x & 0x4000) ? 0x8000 : 0) | ((b.x & 0x2000) ? 0x4000 : 0));
                 if (b.x & 0x2000) s_near = 1;                       // some meshlet of this tile takes the clipping pass below
             }
@@ -1035,11 +1046,14 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
             const int excl = incl - rows;
             const int qpos = bits_below_lane(qmask);
             const int nchunks = (total + 63) >> 6;
+            ROPE_CHECK_INDEX(nchunks - 1, TILE_H > 64 ? TILE_H : 64);
             for (int i = lane; i < nchunks; i += 64) wmask[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (rows > 0) {
+                ROPE_CHECK_INDEX(qpos, 64);
+                ROPE_CHECK_INDEX(excl, 65536);
                 woff[qpos] = excl | (lane << 16);          // first item (total <= 4096) and owner lane of slot qpos
                 atomicOr(&wmask[excl >> 6], 1ull << (excl & 63));
             }
@@ -1140,6 +1154,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams &fp, const RobotPa
                 }
             }
             const unsigned long long km = __ballot(keep);
+            if (keep) ROPE_CHECK_INDEX(ns + bits_below_lane(km), MESHLET_MAX_TRIS);
             if (keep) wkeep[ns + bits_below_lane(km)] = packed;
             ns += __popcll(km);
         }
@@ -1303,6 +1318,7 @@ raster_queue_kernel(FrameParams fp, RobotParams rp, RasterArgs ra, const uint32_
 #pragma unroll
         for (int k = 0; k < QUEUE_CLASSES - 1; k++)
             if (cls == k && place >= cls_n[k]) { place -= cls_n[k]; cls = k + 1; }
+        if (segment) ROPE_CHECK_INDEX(place, segment);
         const uint32_t it = items[(size_t)cls * segment + place];
         raster_tile<LOSS, MODE, CLIP>(fp, rp, ra, (int)(it & 0xFFFFu), (int)(it >> 16), 0, 1);      // row = candidate (MODE_SCORE) or layer (MODE_LAYER)
         __syncthreads();                                   // the tile's LDS is free again
@@ -1359,6 +1375,7 @@ score_queue_kernel(RasterArgs ra, int n_rows, int n_tiles, uint32_t *__restrict_
     __syncthreads();
     if (threadIdx.x < QUEUE_CLASSES) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&counters[2 + threadIdx.x], s_n[threadIdx.x]) : 0;
     __syncthreads();
+    if (mine && segment) ROPE_CHECK_INDEX(s_base[cls] + pos, segment);
     if (mine) items[(size_t)cls * segment + s_base[cls] + pos] = (uint32_t)cand | ((uint32_t)(32 * w + k) << 16);
     if (layers && live && k < ROPE_SUM_WORDS) {
         uint64_t acc = 0;

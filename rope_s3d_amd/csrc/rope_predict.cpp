@@ -23,6 +23,8 @@
 #include "../../include/rope_s3d.h"
 
 void rope_set_error(rope_ctx *c, const std::string &msg);       // rope_abi.hip
+void rope_range_push(const char *name);                         // roctx ranges, one per stage (rope_abi.hip; no-ops without the library)
+void rope_range_pop();
 
 namespace {
 
@@ -498,6 +500,8 @@ int run_stages(rope_ctx *c, const rope_predict_args *a, bool batch, int B, doubl
     for (int i = 0; i < a->n_stages; i++) {
         const rope_stage &s = a->stages[i];
         int rc = ROPE_OK;
+        static const char *const names[] = {"rope:stage:Lookup", "rope:stage:Descent", "rope:stage:SFlip", "rope:stage:InterpolativeSweep", "rope:stage:TensorSweep"};
+        rope_range_push(names[s.kind]);
         switch (s.kind) {
         case ROPE_STAGE_LOOKUP: rc = stage_lookup(m, s, sts); break;
         case ROPE_STAGE_DESCENT: rc = stage_descent(m, s, sts); break;
@@ -505,6 +509,7 @@ int run_stages(rope_ctx *c, const rope_predict_args *a, bool batch, int B, doubl
         case ROPE_STAGE_ISWEEP: rc = stage_isweep(m, s, sts); break;
         case ROPE_STAGE_TSWEEP: rc = stage_tsweep(m, s, sts); break;
         }
+        rope_range_pop();
         if (rc) return rc;
         if (trace_out)
             for (int f = 0; f < B; f++)

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
     'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
     'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
-    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free', 'rope_build_id')
+    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free', 'rope_build_id', 'rope_camera_matrix', 'rope_lookup_grid', 'rope_crop_divisions')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP, STAGE_TSWEEP = 0, 1, 2, 3, 4
@@ -115,6 +115,7 @@ def load_library(path: str = None):
     if hasattr(lib, 'rope_debug_skip'):                 # librope_hip_profile.so only (ROPE_HIP_LIB=...)
         lib.rope_debug_skip.argtypes = [vp, i32]
         lib.rope_debug_clock.argtypes = [vp, vp]
+        lib.rope_debug_bounds.argtypes = [vp, vp]
     lib.rope_predict.argtypes = [vp, C.POINTER(PredictArgs), vp, vp, C.POINTER(C.c_int64)]
     lib.rope_set_robot_mesh.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     lib.rope_partition_mesh.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
@@ -130,6 +131,10 @@ def load_library(path: str = None):
     lib.rope_eval_targets.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.rope_lookup_score_targets.argtypes = [vp, vp, vp, vp]
     lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
+    lib.rope_camera_matrix.argtypes = [vp, dbl, dbl, dbl, dbl, i32, i32, dbl, dbl, vp]
+    lib.rope_crop_divisions.argtypes = [C.c_int64, i32, vp]
+    lib.rope_lookup_grid.argtypes = [vp, vp, vp, C.c_int64]
+    lib.rope_lookup_grid.restype = C.c_int64
     lib.rope_build_id.argtypes = []
     lib.rope_build_id.restype = C.c_char_p
     lib.rope_host_alloc.argtypes = [C.c_size_t]
@@ -493,6 +498,14 @@ class Engine:
         out = np.zeros(2)
         self._check(self._lib.rope_debug_clock(self._ctx, _p(out)), 'rope_debug_clock')
         return float(out[0]), float(out[1])
+
+    def debug_bounds(self) -> int:
+        """Profiling build only: indices into the raster kernels' shared arrays / queue segments found out of range so far."""
+        if not hasattr(self._lib, 'rope_debug_bounds'):
+            raise EngineError("rope_debug_bounds: not in this library; build librope_hip_profile.so and point ROPE_HIP_LIB at it")
+        v = C.c_int()
+        self._check(self._lib.rope_debug_bounds(self._ctx, C.byref(v)), 'rope_debug_bounds')
+        return int(v.value)
 
     def profile_eval(self, n_render: int, loss: int, crop=None, reps: int = 10):
         """-> dict of average milliseconds per pass (HIP events on the engine stream): fk (+bounds), layer (shared

@@ -166,3 +166,32 @@ def view_matrix(pose6) -> np.ndarray:
     V[:3, :3] = R.T
     V[:3, 3] = -R.T @ t
     return V
+
+
+def camera_matrix(pose6, intrinsics: Intrinsics, znear: float = ZNEAR, zfar: float = ZFAR) -> np.ndarray:
+    """P·V of a camera pose and its intrinsics — the matrix the engine, the oracle and a C host all start from.
+
+    One implementation for every caller: rope_camera_matrix in the library (host code, no GPU: the written double operations
+    in the written order, libm's sin / cos), so that the Python Predictor and a plain C host hand the engine the same bits.
+    The numpy expression `intrinsics.gl_projection(znear, zfar) @ view_matrix(pose6)` is the same matrix up to the last digit
+    (its matrix products go through BLAS, whose summation order and fused operations are not ours to fix); it is what runs when
+    the library has not been built."""
+    pose = np.ascontiguousarray(pose6, np.float64).reshape(6)
+    try:
+        import ctypes as C
+        from .engine import EngineUnavailable, load_library
+        try:
+            lib = load_library()
+        except EngineUnavailable:
+            lib = None
+        if lib is not None:
+            PV = np.empty((4, 4))
+            rc = lib.rope_camera_matrix(pose.ctypes.data_as(C.c_void_p), float(intrinsics.fx), float(intrinsics.fy), float(intrinsics.cx),
+                                        float(intrinsics.cy), int(intrinsics.width), int(intrinsics.height), float(znear), float(zfar),
+                                        PV.ctypes.data_as(C.c_void_p))
+            if rc == 0:
+                return PV
+    except ImportError:
+        pass
+    return intrinsics.gl_projection(znear, zfar) @ view_matrix(pose)
+

@@ -12,7 +12,7 @@ import numpy as np
 from ..constants import (BACKGROUND_ID, DEFAULT_RENDER_COLORS, NUM_RENDER_LINKS,
                          RENDERER_FALLBACK_CAMERA_POSE, ZFAR, ZNEAR)
 from ..engine import Engine
-from ..projection import Intrinsics, camera_pose_matrix, view_matrix
+from ..projection import Intrinsics, camera_matrix, camera_pose_matrix, view_matrix
 from ..robot import RobotModel
 from ..urdf import URDFReader
 
@@ -92,7 +92,7 @@ class Renderer:
     def setCameraPose(self, pose_in: np.ndarray):
         """Camera pose with the reference's pitch convention (render.py:107-111)."""
         self._camera_pose6 = np.asarray(pose_in, dtype=np.float64).copy()
-        PV = self.intrinsics.gl_projection(ZNEAR, ZFAR) @ view_matrix(self._camera_pose6)
+        PV = camera_matrix(self._camera_pose6, self.intrinsics, ZNEAR, ZFAR)
         self.engine.set_camera(PV, self.intrinsics.width, self.intrinsics.height, ZNEAR, ZFAR)
 
     def setMode(self, mode: str):

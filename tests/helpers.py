@@ -5,7 +5,7 @@ import numpy as np
 
 from oracle import oracle as orc
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
-from rope_s3d_amd.projection import Intrinsics, view_matrix
+from rope_s3d_amd.projection import Intrinsics, camera_matrix
 from rope_s3d_amd.robot import RobotModel
 from rope_s3d_amd.urdf import URDFReader
 
@@ -23,7 +23,7 @@ def camera(preset='640_480_color', ds=1, pose=DEFAULT_CAMERA_POSE, as_predictor=
         intr.downscale(ds)
     if as_predictor:
         intr = Intrinsics(intr)
-    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(pose)
+    PV = camera_matrix(pose, intr, ZNEAR, ZFAR)          # the one implementation every caller shares (rope_camera_matrix)
     return intr, PV
 
 

@@ -12,10 +12,15 @@ static shim_eval_cb g_cb = nullptr;
 static std::string g_err;
 
 void rope_set_error(rope_ctx *, const std::string &msg) { g_err = msg; }
+static int g_ranges = 0, g_range_depth = 0;
+void rope_range_push(const char *) { g_ranges++; g_range_depth++; }
+void rope_range_pop() { g_range_depth--; }
 
 extern "C" {
 void shim_set_callback(shim_eval_cb cb) { g_cb = cb; }
 const char *shim_last_error() { return g_err.c_str(); }
+int shim_ranges_opened() { return g_ranges; }
+int shim_range_depth() { return g_range_depth; }
 
 int rope_eval(rope_ctx *, const double *cand, int C, int n_render, int loss, const int32_t *crop, double *err_out, uint64_t *,
               int32_t *best_idx, double *)

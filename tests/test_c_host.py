@@ -33,14 +33,15 @@ def test_c_host_builds_and_refuses_to_run_without_a_gpu(exe, tmp_path):
     rb = helpers.robot()
     files = {'verts.f32': rb.verts.astype(np.float32), 'faces.i32': rb.faces.astype(np.int32), 'vtx_off.i32': rb.vtx_off.astype(np.int32),
              'tri_off.i32': rb.tri_off.astype(np.int32), 'joint_fixed.f64': rb.joint_fixed, 'joint_axes.f64': rb.joint_axes,
-             'PV.f64': np.eye(4), 'clip.f64': np.array([.05, 100.]), 'dims.i32': np.array([16, 12], np.int32), 'limits.f64': rb.joint_limits,
-             'camera_pose.f64': np.asarray(DEFAULT_CAMERA_POSE, float), 'tq.u64': np.zeros(192, np.uint64), 't32.f32': np.zeros(192, np.float32),
-             'flags.u8': np.zeros(8, np.uint8), 'grid.f64': np.zeros((8, 6)), 'crop.i32': np.array([0, 11, 0, 15], np.int32)}
+             'limits.f64': rb.joint_limits, 'camera_pose.f64': np.asarray(DEFAULT_CAMERA_POSE, float),
+             'intrinsics.f64': np.array([64, 48, 32.05, 23.7, 61.15, 61.15]), 'setup.i32': np.array([4, 3], np.int32),
+             'link_blue.i32': np.array([0, 42, 85, 127, 170, 212], np.int32), 'color.u8': np.zeros((48, 64, 3), np.uint8),
+             'depth.f32': np.zeros((48, 64), np.float32)}
     for name, a in files.items():
         np.ascontiguousarray(a).tofile(tmp_path / name)
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and 'rope_create' in r.stderr and r.stdout == ''          # no device: says so, computes nothing
-    (tmp_path / 'tq.u64').write_bytes(b'\0' * 8)
+    (tmp_path / 'depth.f32').write_bytes(b'\0' * 8)
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and 'does not match' in r.stderr
 
@@ -57,9 +58,12 @@ def test_c_host_predicts_the_same_angles_as_the_python_host(exe, tmp_path):
         sp.renderer.setJointAngles(q)
         color, depth = sp.renderer.render()
         want = p.run(color, depth)
-        bundle = dump_frame_bundle(str(tmp_path / f'bundle{seed}'), p, p.prepare(color, depth))
+        # the bundle holds inputs only — meshes, chain, limits, camera pose, base intrinsics, the frame: no matrix, crop or grid
+        bundle = dump_frame_bundle(str(tmp_path / f'bundle{seed}'), p, color, depth, '640_480_color', 5)
+        assert not any(os.path.exists(os.path.join(bundle, f)) for f in ('PV.f64', 'crop.i32', 'grid.f64', 'tq.u64', 't32.f32'))
         r = subprocess.run([exe, bundle], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         got = np.array([float(x) for x in r.stdout.split()])
         assert np.array_equal(got, want), (got, want)
-        assert f'{p.evaluations}' != '' and 'candidate poses rendered and scored' in r.stderr
+        c = p.lookup_crop
+        assert f'crop {c[0]} {c[1]} {c[2]} {c[3]}, {len(p.lookup_angles)} lookup poses' in r.stderr

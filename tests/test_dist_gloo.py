@@ -58,10 +58,11 @@ def test_bench_refuses_a_rank_count_that_contradicts_gpus():
 
 def test_bench_starts_its_own_ranks_and_relays_their_failure():
     """Without a launcher's environment `--gpus 2` starts two ranks itself, before anything touches a GPU.  Here there is no
-    GPU, so both children stop with the engine's refusal and the parent hands their failure on."""
+    GPU, so the children stop with the engine's refusal and the parent hands their failure on."""
     import torch
     if torch.cuda.is_available():
         import pytest
         pytest.skip("CPU-only check; the GPU suite runs the two-rank bench for real")
     out = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--backend', 'gloo'], {})
-    assert out.returncode != 0 and out.stderr.count('bench.py needs a GPU') >= 2, out.stderr[-2000:]
+    # the launcher ends the other rank as soon as the first one has failed: one refusal is certain, the second a matter of timing
+    assert out.returncode != 0 and out.stderr.count('bench.py needs a GPU') >= 1, out.stderr[-2000:]

@@ -1,11 +1,13 @@
 """GPU: properties at BASELINE.json's full sizes (640x480, 4096 candidates; 1280x720 mh50), where the CPU oracle
 would take minutes, plus edge cases of the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
 from rope_s3d_amd import engine as eng
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
-from rope_s3d_amd.projection import Intrinsics, view_matrix
+from rope_s3d_amd.projection import Intrinsics, camera_matrix, view_matrix
 
 import helpers
 from oracle import oracle as orc
@@ -261,10 +263,10 @@ def test_frames_of_more_than_256_tiles():
     order in one segment.  600 candidates through the queue equal the one-workgroup-per-pair launch, the unshared form, and the
     oracle on a sample."""
     rb = helpers.robot()
-    from rope_s3d_amd.projection import Intrinsics, view_matrix
+    from rope_s3d_amd.projection import Intrinsics, camera_matrix
     intr = Intrinsics('[ 2560x1440  p[1276.78 722.986]  f[1810.46 1809.72]  Inverse Brown Conrady [0 0 0 0 0] ]')
     assert -(-intr.width // 128) * -(-intr.height // 96) > 256
-    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+    PV = camera_matrix(DEFAULT_CAMERA_POSE, intr, ZNEAR, ZFAR)
     e = eng.Engine(0)
     e.set_robot(rb)
     e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
@@ -440,3 +442,83 @@ def test_cfg5_full_size_grid():
     err_f, sums_f, *_ = e.eval(cand, 6, eng.LOSS_FULL, want_sums=True)
     err_ref, sums_ref = o.eval(cand[pick[:12]], eng.LOSS_FULL, 6, tq, t32, None, flags, threads=16, want_sums=True)
     assert np.array_equal(sums_f[pick[:12]], sums_ref) and np.array_equal(err_f[pick[:12]].view(np.uint64), err_ref.view(np.uint64))
+
+
+@pytest.mark.parametrize('pose,q0', [([0.3, -0.12, 0.77, 0, 0.2, 0.3], [0, 0, 0, 0, 0, 0]), ([0.2, -0.1, 0.6, 0.3, 0.1, -0.4], [0.5, 0.4, 0.6, 0.2, 0.3, 0.1])])
+def test_clipping_kernels_layers_queue_and_every_loss(pose, q0):
+    """The instantiations that clip at the near plane, where they broke before: a camera inside the near plane's reach of the
+    robot (triangles are cut), a batch large enough for the queue with shared layers (a grid over U under 48 (S, L) pairs), the
+    lookup loss with a crop, the depth, full and TensorSweep losses — every launch structure (layers / none / queue / none)
+    gives the same sums, the same sums again on a second and third pass (round 3: the spilled layer-queue clipping kernel did
+    not), and sampled rows equal the oracle's bit for bit (round 2: a memory fault while these kernels were being written)."""
+    rb = helpers.robot()
+    e, intr, PV = make_engine(rb, '640_480_color', pose=pose, ds=2)
+    o = helpers.make_oracle(rb, intr, PV)
+    d_ref, id_ref = o.render(q0, 6)
+    tq, t32, flags, tgt, _, _ = helpers.synthetic_target(d_ref, id_ref)
+    full32 = np.ascontiguousarray(tgt, np.float32)
+    e.set_target(tq, t32, flags)
+    e.set_target_tsweep(full32)
+    rng = np.random.default_rng(41)
+    sl = np.array(q0)[:2] + rng.uniform(-.25, .25, (48, 2))
+    cand = np.zeros((48 * 12, 6))
+    cand[:, :2] = np.repeat(sl, 12, axis=0)
+    cand[:, 2] = np.tile(np.array(q0)[2] + np.linspace(-.4, .4, 12), 48)
+    cand[:, 3:] = np.array(q0)[3:]
+    H, W = intr.height, intr.width
+    crop = [int(H * .15), int(H * .9), int(W * .1), int(W * .95)]
+    pick = np.sort(rng.choice(len(cand), 10, replace=False))
+    for loss in (eng.LOSS_LOOKUP, eng.LOSS_DEPTH, eng.LOSS_FULL, eng.LOSS_TSWEEP):
+        cr = crop if loss == eng.LOSS_LOOKUP else None
+        _, base, bi, _ = e.eval(cand, 6, loss, crop=cr, want_sums=True)
+        for flag in (0, 0, e.NO_LAYERS, e.NO_QUEUE, e.NO_LAYERS | e.NO_QUEUE, e.NO_PARENTS):
+            e.set_strategy(flag)
+            try:
+                _, again, bi2, _ = e.eval(cand, 6, loss, crop=cr, want_sums=True)
+            finally:
+                e.set_strategy(0)
+            assert np.array_equal(again, base) and bi2 == bi, (loss, flag)
+        t_plane = full32 if loss == eng.LOSS_TSWEEP else t32
+        err_ref, sums_ref = o.eval(cand[pick], loss, 6, tq, t_plane, cr, flags, threads=8, want_sums=True)
+        assert np.array_equal(base[pick], sums_ref), loss
+        # small batches (the split path) through the clipping instantiations as well
+        _, few, *_ = e.eval(cand[pick[:3]], 6, loss, crop=cr, want_sums=True)
+        assert np.array_equal(few, sums_ref[:3]), loss
+
+
+def test_profiling_build_finds_no_index_out_of_range(tmp_path):
+    """The profiling build of the library (-DROPE_PROFILE) checks every index into the raster kernels' shared arrays and queue
+    segments at run time: the clipping test above, the bench grid and a small batch leave the violation count at zero."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), os.pardir))
+    lib = os.path.join(root, 'rope_s3d_amd', 'csrc', 'librope_hip_profile.so')
+    if not os.path.exists(lib):
+        pytest.skip("librope_hip_profile.so not built (python tools/build_variants.py profile)")
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import helpers
+        from rope_s3d_amd import engine as eng
+        from rope_s3d_amd.constants import ZFAR, ZNEAR
+        rb = helpers.robot()
+        for pose, ds in (([0.3, -0.12, 0.77, 0, 0.2, 0.3], 2), ([0, -1.5, 0.75, 0, 0, 0], 1)):
+            intr, PV = helpers.camera('640_480_color', ds=ds, pose=pose)
+            e = eng.Engine(0)
+            e.set_robot(rb)
+            e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+            d, ids = e.render([0, 0, 0, 0, 0, 0], 6)
+            tq, t32, flags, *_ = helpers.synthetic_target(d, ids)
+            e.set_target(tq, t32, flags)
+            cand = helpers.slu_grid(rb.joint_limits, 12 if ds == 2 else 16) * 0.3
+            for loss, crop in ((eng.LOSS_FULL, None), (eng.LOSS_LOOKUP, [10, intr.height - 10, 10, intr.width - 10])):
+                for flag in (0, e.CLIP_KERNELS, e.NO_LAYERS, e.NO_QUEUE):
+                    e.set_strategy(flag)
+                    e.eval(cand, 6, loss, crop=crop)
+                    e.eval(cand[:5], 6, loss, crop=crop)
+            assert e.debug_bounds() == 0, e.debug_bounds()
+        print('bounds ok')
+    ''') % (root, os.path.join(root, 'tests'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ROPE_HIP_LIB=lib))
+    assert r.returncode == 0 and 'bounds ok' in r.stdout, r.stdout + r.stderr

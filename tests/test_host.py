@@ -604,3 +604,77 @@ def test_native_synthetic_preparation_equals_the_numpy_steps():
         tq2 = np.empty_like(tq)
         assert prepare_synthetic(tall_c[::2], tall_d[::2], f, [color_dict[n][0] for n in names], 6, tq2, t32, flags, None) and np.array_equal(tq2, tq)
         assert not prepare_synthetic(color[:, ::-1], depth, f, [color_dict[n][0] for n in names], 6, tq2, t32, flags, None)
+
+
+def test_camera_matrix_and_lookup_grid_in_the_library():
+    """rope_camera_matrix / rope_lookup_grid (host-only entry points a C host starts from) against the Python restatements of the
+    reference: the pose convention of Renderer.setCameraPose + angToPoseArr and pyrender's IntrinsicsCamera projection written
+    out with math.sin / math.cos (the same libm: bit for bit), the numpy expression the tests used before (BLAS products: equal to
+    the last digits), and lookup.py's grid order bit for bit."""
+    import ctypes as C
+    import math
+    from rope_s3d_amd.constants import ZFAR, ZNEAR
+    from rope_s3d_amd.engine import load_library
+    from rope_s3d_amd.projection import Intrinsics, camera_matrix, view_matrix
+    from rope_s3d_amd.simulation.lookup import lookup_grid
+    lib = load_library()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def by_hand(pose, intr, n, f):
+        x, y, z, a3, a4, a5 = [float(v) for v in pose]
+        yaw, pitch, roll = a5, a3, a4 + math.pi / 2
+        c0, c1, c2, s0, s1, s2 = math.cos(yaw), math.cos(pitch), math.cos(roll), math.sin(yaw), math.sin(pitch), math.sin(roll)
+        R = [[c0 * c1, c0 * s1 * s2 - c2 * s0, s0 * s2 + c0 * c2 * s1],
+             [c1 * s0, c0 * c2 + (s0 * s1) * s2, c2 * s0 * s1 - c0 * s2],
+             [-1 * s1, c1 * s2, c1 * c2]]
+        V = [[R[0][i], R[1][i], R[2][i], -((R[0][i] * x + R[1][i] * y) + R[2][i] * z)] for i in range(3)] + [[0.0, 0.0, 0.0, 1.0]]
+        W, H = float(intr.width), float(intr.height)
+        P00, P11, P02, P12 = 2.0 * intr.fx / W, 2.0 * intr.fy / H, 1.0 - 2.0 * intr.cx / W, 2.0 * intr.cy / H - 1.0
+        P22, P23 = (f + n) / (n - f), (2.0 * f * n) / (n - f)
+        return np.array([[P00 * V[0][j] + P02 * V[2][j] for j in range(4)], [P11 * V[1][j] + P12 * V[2][j] for j in range(4)],
+                         [P22 * V[2][j] + P23 * V[3][j] for j in range(4)], [-V[2][j] for j in range(4)]])
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        pose = np.array([0, -1.5, .75, 0, 0, 0]) + (rng.uniform(-1, 1, 6) * [1, 1, 1, .6, .6, 3.0] if k else 0)
+        intr = Intrinsics(('640_480_color', '1280_720_color')[k % 2])
+        if k % 3:
+            intr.downscale((2, 4, 8)[k % 3])
+        got = camera_matrix(pose, intr, ZNEAR, ZFAR)
+        assert np.array_equal(got.view(np.uint64), by_hand(pose, intr, ZNEAR, ZFAR).view(np.uint64)), k
+        blas = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(pose)
+        assert np.allclose(got, blas, rtol=1e-12, atol=1e-14)
+    bad = np.empty(16)
+    pose = np.zeros(6)
+    assert lib.rope_camera_matrix(p(pose), 600., 600., 320., 240., 640, 480, 0.05, 0.01, p(bad)) == -1       # zfar <= znear
+    lim = helpers.robot().joint_limits
+    lim_c = np.ascontiguousarray(lim, np.float64)
+    for varying, div in (('SLU', [16, 16, 16, 1, 1, 1]), ('SLU', [25, 25, 25, 0, 0, 0]), ('SL', [4, 7, 9, 9, 9, 9]), ('SLURB', [3, 2, 5, 1, 4, 1]), ('U', [0, 0, 300, 0, 0, 0])):
+        want = lookup_grid(lim, varying, div)
+        d = np.array([dv if c in varying else 0 for c, dv in zip('SLURBT', div)], np.int32)
+        n = lib.rope_lookup_grid(p(lim_c), p(d), None, 0)
+        assert n == len(want)
+        got = np.empty((n, 6))
+        assert lib.rope_lookup_grid(p(lim_c), p(d), p(got), n) == n and np.array_equal(got.view(np.uint64), want.view(np.uint64)), (varying, div)
+        assert lib.rope_lookup_grid(p(lim_c), p(d), p(got), n - 1) == -1
+
+
+def test_crop_grid_from_the_library_equals_crop_py():
+    """rope_crop_divisions + rope_lookup_grid = crop.crop_pose_grid (robotpose/crop.py:114-146) for every link count and image
+    size the callers use: the same poses, bit for bit, in the same order."""
+    import ctypes as C
+    from rope_s3d_amd.crop import crop_pose_grid
+    from rope_s3d_amd.engine import load_library
+    lib = load_library()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lim = np.ascontiguousarray(helpers.robot().joint_limits, np.float64)
+    for size in (160 * 90, 160 * 120, 320 * 240, 640 * 480, 1280 * 720, 80 * 60):
+        for n_links in range(2, 7):
+            want, divisions = crop_pose_grid(lim, size, n_links)
+            d = np.zeros(6, np.int32)
+            assert lib.rope_crop_divisions(size, n_links, p(d)) == 0
+            assert [int(x) for x in d] == [int(divisions[j]) if j in (0, 1, 2, 4) else 0 for j in range(6)], (size, n_links, d, divisions)
+            n = lib.rope_lookup_grid(p(lim), p(d), None, 0)
+            got = np.empty((n, 6))
+            assert n == len(want) and lib.rope_lookup_grid(p(lim), p(d), p(got), n) == n
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (size, n_links)
+    assert lib.rope_crop_divisions(100, 1, p(d)) == -1 and lib.rope_crop_divisions(100, 7, p(d)) == -1

@@ -105,6 +105,7 @@ def test_stage_loop_against_sequential_reference(shim, do_angles, seed, speculat
         # the serial order asks for exactly the reference's renders, minus the lower-limit render SFlip throws away
         assert n_eval - 4 <= n.value <= n_eval
     assert calls[0] == len(grid) and max(calls[1:]) <= 26          # the lookup grid, then batches of at most 1 + 25 poses
+    assert shim.shim_ranges_opened() >= len(stages) and shim.shim_range_depth() == 0      # one named range per stage, all closed
 
 
 def test_frames_in_lockstep_equal_frame_by_frame(shim):

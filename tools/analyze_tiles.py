@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR          # noqa: E402
-from rope_s3d_amd.projection import Intrinsics, view_matrix                  # noqa: E402
+from rope_s3d_amd.projection import Intrinsics, camera_matrix                  # noqa: E402
 from rope_s3d_amd.robot import RobotModel                                    # noqa: E402
 from rope_s3d_amd.simulation.kinematics import ForwardKinematics            # noqa: E402
 
@@ -20,7 +20,7 @@ def main():
     ml = rb.meshlets
     intr = Intrinsics('640_480_color')
     W, H = intr.width, intr.height
-    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+    PV = camera_matrix(DEFAULT_CAMERA_POSE, intr, ZNEAR, ZFAR)
     fk = ForwardKinematics(rb)
     M = len(ml.header)
     link = ml.header[:, 7].astype(int)

@@ -7,12 +7,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.p
 from bench import slu_grid
 from rope_s3d_amd import engine as eng
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
-from rope_s3d_amd.projection import Intrinsics, view_matrix
+from rope_s3d_amd.projection import Intrinsics, camera_matrix
 from rope_s3d_amd.robot import RobotModel
 
 robot = RobotModel.from_urdf()
 intr = Intrinsics('640_480_color')
-PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+PV = camera_matrix(DEFAULT_CAMERA_POSE, intr, ZNEAR, ZFAR)
 e = eng.Engine(0)
 e.set_robot(robot)
 e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)

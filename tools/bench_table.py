@@ -5,14 +5,14 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 from rope_s3d_amd import engine as eng
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
-from rope_s3d_amd.projection import Intrinsics, view_matrix
+from rope_s3d_amd.projection import Intrinsics, camera_matrix
 from rope_s3d_amd.robot import RobotModel
 from rope_s3d_amd.simulation.lookup import lookup_grid
 
 robot = RobotModel.from_urdf()
 for preset, ds, d in (('1280_720_color', 8, 25), ('640_480_color', 1, 16)):
     intr = Intrinsics(preset); intr.downscale(ds)
-    PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+    PV = camera_matrix(DEFAULT_CAMERA_POSE, intr, ZNEAR, ZFAR)
     e = eng.Engine(0); e.set_robot(robot); e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
     depth, ids = e.render([0.3, 0.4, 0.9, 0, 0, 0], 6)
     e.set_target(eng.pack_target(depth.astype(np.float64)), depth, np.zeros(8, np.uint8))

@@ -9,14 +9,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), os.p
 from bench import slu_grid
 from rope_s3d_amd import engine as eng  # noqa: E402
 from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
-from rope_s3d_amd.projection import Intrinsics, view_matrix
+from rope_s3d_amd.projection import Intrinsics, camera_matrix
 from rope_s3d_amd.robot import RobotModel
 
 grid = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 LOSS = {'depth': eng.LOSS_DEPTH, 'full': eng.LOSS_FULL}[sys.argv[2] if len(sys.argv) > 2 else 'depth']
 robot = RobotModel.from_urdf()
 intr = Intrinsics('640_480_color')
-PV = intr.gl_projection(ZNEAR, ZFAR) @ view_matrix(DEFAULT_CAMERA_POSE)
+PV = camera_matrix(DEFAULT_CAMERA_POSE, intr, ZNEAR, ZFAR)
 e = eng.Engine(0)
 e.set_robot(robot)
 e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
