@@ -77,3 +77,22 @@ def test_predictor_reproduces_golden_trace():
     got = np.stack([a for _, a in sp.predictor.trace])
     assert np.array_equal(got, G['frame_trace']) and np.array_equal(predicted, G['frame_final'])
     assert np.abs(predicted - G['frame_q_true'])[:3].max() < 0.05
+
+
+@pytest.mark.gpu
+def test_engine_renders_equal_the_independent_exact_rasteriser():
+    """The HIP engine against tests/golden/pins_raster_160x120.npz (an independent rasteriser in Python integers over the real mesh,
+    tests/golden/make_pins.py): same covered pixels, same link on every pixel."""
+    from rope_s3d_amd import engine as eng
+    pins = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pins_raster_160x120.npz'))
+    rb = helpers.robot()
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    e = eng.Engine(0)
+    e.set_robot(rb)
+    e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+    for k, q in enumerate(pins['poses']):
+        depth, ids = e.render(q, 6)
+        near = pins[f'near{k}']
+        assert np.array_equal(ids != 255, pins[f'ids{k}'] != 255) and np.array_equal(ids[~near], pins[f'ids{k}'][~near]), k
+        assert ((depth != 0) == (ids != 255)).all()
+

@@ -1,5 +1,7 @@
 """Closed-form pins of the CPU oracle (the reference ships no tests or fixtures for this path, so
 these hand-derived expectations are what anchors the oracle: SURVEY.md §8c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -249,3 +251,60 @@ def test_eval_batch_threads_agree(frame):
     a = o.eval(cand, orc.LOSS_FULL, 6, tq, t32, None, flags, threads=1)
     b = o.eval(cand, orc.LOSS_FULL, 6, tq, t32, None, flags, threads=4)
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_oracle_rasteriser_against_the_independent_exact_one():
+    """tests/golden/pins_raster_160x120.npz: the REAL mh5l mesh at three poses through an independent rasteriser in Python integers
+    and exact rationals (tests/golden/make_pins.py: hand-rounded float32 vertex shading, brute-force edge functions per pixel with
+    the top-left rule, exact barycentric depth).  The C oracle must cover exactly the same pixels, give every pixel the same link,
+    and its 24-bit depth (a float32 plane, quantised) must sit within two units of the exact value."""
+    pins = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pins_raster_160x120.npz'))
+    rb = helpers.robot()
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    o = helpers.make_oracle(rb, intr, PV)
+    for k, q in enumerate(pins['poses']):
+        key = o.raster_key(q, 6)
+        ids = np.where(key == 0xFFFFFFFF, 255, key & 0xFF).astype(np.uint8)
+        want_ids, want_d24, near = pins[f'ids{k}'], pins[f'd24_{k}'], pins[f'near{k}']
+        assert (want_ids != 255).sum() > 1000
+        assert np.array_equal(ids != 255, want_ids != 255), f"pose {k}: coverage differs"
+        assert np.array_equal(ids[~near], want_ids[~near]), f"pose {k}: link ids differ"
+        drawn = want_ids != 255
+        assert np.abs((key >> 8).astype(np.int64) - want_d24.astype(np.int64))[drawn & ~near].max() <= 2
+        # and the metric depth read-back of those keys is pyrender's formula on the quantised value
+        depth, _ = o.resolve(key)
+        d = want_d24[drawn].astype(np.float64) / (2 ** 24 - 1)
+        z = 2 * 0.05 * 100.0 / (100.0 + 0.05 - (2 * d - 1) * (100.0 - 0.05))
+        assert np.abs(depth[drawn] - z).max() < 2e-6 * z.max() + 4 * 2.0 ** -24 * z.max() ** 2 / 0.05
+
+
+def test_box_morphology_against_scipy_ndimage():
+    """imgproc.dilate / imgproc.erode (cv2.dilate / cv2.erode with a ones(k, k) kernel, default anchor (k // 2, k // 2) — for an even
+    k the window reaches one sample further up/left than down/right — and a border that never wins) against scipy.ndimage's
+    maximum_filter / minimum_filter as a second implementation: the body mask's dilate 8 / erode 7 (predict.py:428,437) and every
+    kernel size NoiseMaker.holes uses (3..24, noise.py:20,26).  cv2 itself is not installed anywhere this runs: what this pins is
+    that the window geometry written down in imgproc.py is computed correctly, twice."""
+    from scipy import ndimage
+    from rope_s3d_amd import imgproc
+    rng = np.random.default_rng(9)
+    for k in list(range(3, 25)) + [7, 8]:
+        for shape in ((45, 80), (31, 33)):
+            img = (rng.uniform(size=shape) > 0.93).astype(np.float64) * rng.uniform(0.5, 2.0, shape)
+            # scipy's window for size k and origin o covers [x - k // 2 - o, x + (k - 1) // 2 - o]; OpenCV's anchor k // 2 covers
+            # [x - k // 2, x + k - 1 - k // 2]: the same window for odd AND even k with origin 0
+            want_d = ndimage.maximum_filter(img, size=k, mode='constant', cval=-np.inf, origin=0)
+            want_e = ndimage.minimum_filter(img, size=k, mode='constant', cval=np.inf, origin=0)
+            assert np.array_equal(imgproc.dilate(img, k), want_d), k
+            assert np.array_equal(imgproc.erode(img, k), want_e), k
+            # hand check of the geometry on one sample, away from the borders
+            y, x, a = shape[0] // 2, shape[1] // 2, k // 2
+            if y - a >= 0 and x - a >= 0 and y - a + k <= shape[0] and x - a + k <= shape[1]:
+                assert want_d[y, x] == img[y - a:y - a + k, x - a:x - a + k].max()
+    # the body mask of the segmentation path: erode7(dilate8(.)) of a blob keeps the blob and closes holes up to 7 wide
+    blob = np.zeros((40, 60))
+    blob[10:30, 15:45] = 1
+    blob[18:21, 25:31] = 0
+    body = imgproc.erode(imgproc.dilate(blob, 8), 7)
+    assert body[18:21, 25:31].all() and np.array_equal(body, ndimage.minimum_filter(ndimage.maximum_filter(blob, 8, mode='constant', cval=-np.inf), 7,
+                                                                                    mode='constant', cval=np.inf))
+
