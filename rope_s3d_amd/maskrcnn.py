@@ -218,10 +218,13 @@ def _conv_act(conv: nn.Conv2d, x: torch.Tensor, res: torch.Tensor = None, relu: 
 
 
 def _apply_deltas(boxes, deltas):
+    """Matterport apply_box_deltas_graph, step for step (the far corner is the near one plus the size, not centre plus half)."""
     h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
-    cy, cx = boxes[:, 0] + 0.5 * h + deltas[:, 0] * h, boxes[:, 1] + 0.5 * w + deltas[:, 1] * w
+    cy, cx = boxes[:, 0] + 0.5 * h, boxes[:, 1] + 0.5 * w
+    cy, cx = cy + deltas[:, 0] * h, cx + deltas[:, 1] * w
     h, w = h * deltas[:, 2].exp(), w * deltas[:, 3].exp()
-    return torch.stack([cy - 0.5 * h, cx - 0.5 * w, cy + 0.5 * h, cx + 0.5 * w], 1)
+    y1, x1 = cy - 0.5 * h, cx - 0.5 * w
+    return torch.stack([y1, x1, y1 + h, x1 + w], 1)
 
 
 def _iou_over(a: torch.Tensor, b: torch.Tensor, thr: float) -> torch.Tensor:
@@ -590,26 +593,41 @@ class MaskRCNN(nn.Module):
         sel = sel[first_n(frame[sel], DETECTION_MAX_INSTANCES)]
         sel = sel[frame[sel].argsort(stable=True)]                          # frame-major, best first inside a frame
         det_boxes, det_cls, det_score, det_frame = refined[sel], cls_id[sel], score[sel], frame[sel]
+        sel_all, det_boxes_all = sel, det_boxes
         m = self.mask(_roi_align(feats, _pad_rows(det_boxes, MASK_ROW_STEP), MASK_POOL_SIZE, self.size, _pad_rows(det_frame, MASK_ROW_STEP),
                                  packed))[:len(sel)].float().sigmoid()
         m = m[torch.arange(len(sel), device=dev), det_cls]                  # (K, 28, 28) of each detection's class
-        # un-mould: boxes back to original image pixels, masks resized into their box (utils.unmold_mask)
-        px = det_boxes * (self.size - 1) + _const([0, 0, 1, 1], dev)
-        px = ((px - _const([top, left, top, left], dev)) / scale).round().long()
-        # every detection's 28x28 mask is resized into its (clipped) box — all of them in one sampling pass over the
-        # image grid: pixel centre (Y+0.5, X+0.5) of box [y1,y2)x[x1,x2) looks up the mask at ((Y+0.5-y1)/(y2-y1), ...),
-        # which is the bilinear resize with half-pixel centres and edge clamping that the per-box resize computes
-        y1, x1 = px[:, 0].clamp(min=0), px[:, 1].clamp(min=0)
-        y2, x2 = px[:, 2].clamp(max=H), px[:, 3].clamp(max=W)
+        # un-mould (MaskRCNN.unmold_detections): boxes relative to the window, normalised as utils.norm_boxes does (float32), then
+        # utils.denorm_boxes onto the ORIGINAL image: round-half-even of box * (H - 1, W - 1) + (0, 0, 1, 1) in float64
+        wn = ((window.double() - _const([0, 0, 1, 1], dev, torch.float64)) / (self.size - 1)).float()
+        shift = torch.stack([wn[0], wn[1], wn[0], wn[1]])
+        span = torch.stack([wn[2] - wn[0], wn[3] - wn[1], wn[2] - wn[0], wn[3] - wn[1]])
+        rel = (det_boxes - shift) / span
+        px = (rel.double() * _const([H - 1, W - 1, H - 1, W - 1], dev, torch.float64) + _const([0, 0, 1, 1], dev, torch.float64)).round().long()
+        ok = (px[:, 2] - px[:, 0]) * (px[:, 3] - px[:, 1]) > 0                     # zero-area boxes are dropped (exclude_ix)
+        if not bool(ok.all()):
+            px, m, det_cls, det_score, det_frame = px[ok], m[ok], det_cls[ok], det_score[ok], det_frame[ok]
+        # utils.unmold_mask: every detection's 28x28 mask resized to its box (skimage.transform.resize, order 1, mode 'constant',
+        # cval 0: output sample r looks at (r + 0.5) * 28 / h - 0.5, and what lies outside the mask counts as 0), >= 0.5, pasted at
+        # the box — all detections in one sampling pass over the image grid: pixel (Y, X) of a box starting at (y1, x1) is its
+        # sample (Y - y1, X - x1), which grid_sample's half-pixel convention with zero padding reads at 2 (Y + 0.5 - y1) / h - 1
+        y1r, x1r, y2r, x2r = px[:, 0], px[:, 1], px[:, 2], px[:, 3]
+        y1, x1 = y1r.clamp(min=0), x1r.clamp(min=0)
+        y2, x2 = y2r.clamp(max=H), x2r.clamp(max=W)
         Y = torch.arange(H, device=dev, dtype=torch.float32)[None, :, None] + 0.5
         X = torch.arange(W, device=dev, dtype=torch.float32)[None, None, :] + 0.5
-        hh, ww = (y2 - y1).clamp(min=1).float()[:, None, None], (x2 - x1).clamp(min=1).float()[:, None, None]
-        gy = 2 * (Y - y1.float()[:, None, None]) / hh - 1
-        gx = 2 * (X - x1.float()[:, None, None]) / ww - 1
+        hh, ww = (y2r - y1r).clamp(min=1).float()[:, None, None], (x2r - x1r).clamp(min=1).float()[:, None, None]
+        gy = 2 * (Y - y1r.float()[:, None, None]) / hh - 1
+        gx = 2 * (X - x1r.float()[:, None, None]) / ww - 1
         grid = torch.stack([gx.expand(-1, H, W), gy.expand(-1, H, W)], -1)
-        val = F.grid_sample(m[:, None], grid, mode='bilinear', padding_mode='border', align_corners=False)[:, 0]
+        val = F.grid_sample(m[:, None], grid, mode='bilinear', padding_mode='zeros', align_corners=False)[:, 0]
         inside = (Y > y1[:, None, None]) & (Y < y2[:, None, None]) & (X > x1[:, None, None]) & (X < x2[:, None, None])
         masks = (val >= 0.5) & inside                                       # (K, H, W)
+        if getattr(self, 'keep_trace', False):          # tests hold every decision of the stage against oracle/maskrcnn_ref.py
+            self.trace = dict(anchors=anchors, probs=probs, deltas=deltas, top_idx=top_idx, top_p=top_p, decoded=boxes, keep=keep, rois=rois,
+                              roi_frame=frame, cls_prob=cls_prob, box_delta=box_delta, refined=refined, sel=sel_all, ok=ok, det_boxes=det_boxes_all,
+                              det_cls=det_cls, det_score=det_score, det_frame=det_frame, mask28=m, px=px, resized=val, window=window,
+                              feats=feats, geometry=(H, W, scale, top, left, nh, nw))
         if dev.type == 'cuda':                                              # one transfer for the whole batch, through pinned memory
             host = torch.empty(masks.shape, dtype=torch.bool, pin_memory=True)
             host.copy_(masks, non_blocking=True)

@@ -447,3 +447,95 @@ def test_hip_bias_act_equals_the_separate_tensor_operations(monkeypatch):
                 assert got.stride() == want.stride() and torch.equal(got.view(torch.int16), want.view(torch.int16)), (cl, r is not None, relu)
         finally:
             monkeypatch.setattr(M.F, 'conv2d', real_conv2d)
+
+
+def _stage_against_oracle(device: str, n_frames: int, size=(90, 160), seed: int = 5):
+    """Every decision of the post-trunk stage (MaskRCNN._detect) against oracle/maskrcnn_ref.py, the numpy restatement of Matterport's
+    published steps, one box at a time.  Each step of the oracle is fed what the product fed ITS step (so that a last-digit
+    difference in exp() cannot cascade), and compared: values to float32 round-off, decisions — which boxes survive, in which order,
+    with which class, which pixels the integer masks hold — exactly."""
+    from oracle import maskrcnn_ref as ref
+    from rope_s3d_amd.maskrcnn import DETECTION_MAX_INSTANCES, MaskRCNNSegmenter, _roi_align
+    seg = MaskRCNNSegmenter(7, device=device, seed=seed, min_confidence=0.0)
+    net = seg.net
+    net.keep_trace = True
+    net.min_conf = 0.142                              # random weights put the class scores just above 1/7: a threshold that really filters
+    rng = np.random.default_rng(seed)
+    frames = [rng.integers(0, 255, size + (3,), dtype=np.uint8) for _ in range(n_frames)]
+    out = seg.batch(frames)
+
+    def host(v):
+        if torch.is_tensor(v):
+            return (v.detach().float() if v.dtype.is_floating_point else v.detach()).cpu().numpy()
+        return v
+    t = {k: host(v) for k, v in net.trace.items() if k != 'feats'}
+    feats = [host(x) for x in net.trace['feats'][:4]]                                       # (B, C, h, w) each
+    H, W, scale, top, left, nh, nw = t['geometry']
+    anchors, sel, ok = t['anchors'], [int(i) for i in t['sel']], t['ok']
+    nwin = (np.array([top, left, top + nh, left + nw], np.float32) - np.array([0, 0, 1, 1], np.float32)) / np.float32(net.size - 1)
+    checked = dict(proposals=0, detections=0, mask_pixels=0, near=0)
+    roi_at = det_at = 0
+    for f in range(n_frames):
+        # ---- ProposalLayer: decode + clip of the top anchors (values), then NMS on the product's boxes (decisions)
+        top_idx, top_p = t['top_idx'][f], t['top_p'][f]
+        order = sorted(range(len(t['probs'][f])), key=lambda i: (-float(t['probs'][f][i]), i))[:len(top_idx)]
+        assert np.array_equal(np.sort(np.asarray(order)), np.sort(top_idx))              # the same anchors enter
+        for j in rng.choice(len(top_idx), 200, replace=False):
+            want = ref.clip_box(ref.apply_box_delta(anchors[top_idx[j]], t['deltas'][f][top_idx[j]] * ref.RPN_BBOX_STD_DEV), (0, 0, 1, 1))
+            assert np.allclose(t['decoded'][f][j], want, rtol=0, atol=2e-6), (f, j)
+        keep_ref = ref.non_max_suppression(t['decoded'][f], top_p, ref.POST_NMS_ROIS, ref.RPN_NMS_THRESHOLD)
+        keep_got = np.flatnonzero(t['keep'][f])
+        assert list(keep_got) == sorted(keep_ref) and len(keep_ref) > 50, f                # the same proposals, by anchor rank
+        n_roi = len(keep_ref)
+        rois = t['rois'][roi_at:roi_at + n_roi]
+        assert np.array_equal(rois, t['decoded'][f][keep_got]) and (t['roi_frame'][roi_at:roi_at + n_roi] == f).all()
+        checked['proposals'] += n_roi
+        # ---- refine_detections_graph on the product's head outputs for these proposals
+        keep, cls, sc, boxes = ref.refine_detections(rois, t['cls_prob'][roi_at:roi_at + n_roi], t['box_delta'][roi_at:roi_at + n_roi], nwin,
+                                                     net.min_conf, DETECTION_MAX_INSTANCES)
+        sel_f = [i - roi_at for i in sel if roi_at <= i < roi_at + n_roi]
+        assert sel_f == keep, (f, sel_f[:10], keep[:10])                                  # the same detections in the same order
+        n_det = len(keep)
+        assert np.allclose(t['det_boxes'][det_at:det_at + n_det], boxes, rtol=0, atol=2e-6)
+        # ---- unmold_detections: pixel boxes and integer masks
+        rows = list(range(det_at, det_at + n_det))                                        # rows of this frame among all detections
+        kept_rows = list(np.flatnonzero(ok))                                              # ... and the product's rows after the zero-area filter
+        m28 = [t['mask28'][kept_rows.index(r)] if ok[r] else np.zeros((28, 28), np.float32) for r in rows]
+        bx, masks, kept = ref.unmold_detections([t['det_boxes'][r] for r in rows], m28, (H, W), (net.size, net.size),
+                                                [top, left, top + nh, left + nw])
+        assert [rows[k] for k in kept] == [r for r in rows if ok[r]]                       # the same zero-area boxes are dropped
+        got_cls, got_masks = out[f]['class_ids'], out[f]['masks']
+        assert list(got_cls) == [cls[k] for k in kept] and got_masks.shape == (H, W, len(kept))
+        for k, (full, vals, box) in enumerate(masks):
+            assert np.array_equal(t['px'][kept_rows.index(rows[kept[k]])], box), (f, k)
+            # float32 bilinear weights against float64 ones: a resized value within 1e-5 of the threshold may fall either side
+            near = np.zeros((H, W), bool)
+            y1, x1, y2, x2 = max(box[0], 0), max(box[1], 0), min(box[2], H), min(box[3], W)
+            near[y1:y2, x1:x2] = (np.abs(vals - 0.5) < 1e-5)[y1 - box[0]:y2 - box[0], x1 - box[1]:x2 - box[1]]
+            assert np.array_equal(got_masks[..., k][~near], full[~near]), (f, k, int((got_masks[..., k] != full).sum()))
+            checked['mask_pixels'] += int(full.sum())
+            checked['near'] += int(near.sum())
+        checked['detections'] += n_det
+        det_at += n_det
+        roi_at += n_roi
+    # (random weights leave the mask logits near 0, i.e. the values near the 0.5 threshold: a per cent of the pixels are too close to call)
+    assert checked['detections'] >= 2 * n_frames and checked['mask_pixels'] > 1000 and checked['near'] < 0.05 * checked['mask_pixels'], checked
+    # ---- PyramidROIAlign on a few proposals of frame 0: level rule exact, samples to the features' precision
+    got = _roi_align(net.trace['feats'], torch.from_numpy(t['rois'][:12].copy()).to(device), 7, net.size).float().cpu().numpy()      # (12, C, 7, 7)
+    tol = 3e-2 if device != 'cpu' else 1e-5                                                # bfloat16 features on the GPU
+    for k in range(12):
+        lv = ref.roi_level(t['rois'][k], net.size)
+        want = ref.crop_and_resize(feats[lv - 2][0].transpose(1, 2, 0).astype(np.float64), t['rois'][k], 7).transpose(2, 0, 1)
+        assert np.allclose(got[k], want, rtol=tol, atol=tol * max(1.0, float(np.abs(want).max()))), (k, lv)
+    return checked
+
+
+def test_post_trunk_stage_against_the_matterport_restatement_cpu():
+    _stage_against_oracle('cpu', 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_frames', [1, 8])
+def test_post_trunk_stage_against_the_matterport_restatement_gpu(n_frames):
+    """The same with the HIP kernels of csrc/rope_seg.hip in the stage (NMS, RoIAlign, bias/activation), batches of 1 and 8."""
+    _stage_against_oracle('cuda:0', n_frames)
