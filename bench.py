@@ -125,6 +125,35 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None,
                       f"{dt:.2f} s wall; single thread: first {len(one)} candidates, {dt1:.2f} s"}
 
 
+def end_to_end(device, n_frames=256):
+    """The whole prediction path at the metric's resolution on one engine context, after the timed region: n_frames synthetic
+    640x480 RGB-D frames (already in host memory, as a camera or a dataset reader hands them over) through Predictor.run_many —
+    host preparation, upload, the Lookup stage (9^3 grid, the reference's size rule) and every stage of the 'SLU' list, the frames
+    walking the stage list in lockstep batches (rope_predict_batch).  Poses = candidate poses rendered AND scored, lookup rows
+    included.  Not `value`: an extra figure beside it."""
+    from rope_s3d_amd import SyntheticPredictor
+    from rope_s3d_amd.constants import DEFAULT_CAMERA_POSE
+    sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, '640_480_color', 1, 'SLU', noise=False, seed=1, device=device)
+    p = sp.predictor
+    lim = sp.urdf_reader.joint_limits
+    frames = []
+    for f in range(n_frames):
+        sp.renderer.setJointAngles(np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]))
+        frames.append(sp.renderer.render())
+    colors, depths = [c for c, _ in frames], [d for _, d in frames]
+    p.run_many(colors[:128], depths[:128])                      # warm-up: buffers of a batch's size
+    p.evaluations = 0
+    t0 = time.perf_counter()
+    got = p.run_many(colors, depths)
+    dt = time.perf_counter() - t0
+    truth = np.array([np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]) for f in range(n_frames)])
+    return {"frames_per_s": n_frames / dt, "poses_per_s": p.evaluations / dt, "frames": n_frames,
+            "evaluations_per_frame": p.evaluations / n_frames, "lookup_grid": int(len(p.lookup_angles)),
+            "median_abs_joint_error_rad": float(np.median(np.abs(got - truth)[:, :3])),
+            "workload": "640x480 / 1, 'SLU' stage list, one Predictor (one engine context), frames in lockstep batches; "
+                        "frames in host memory when the clock starts, angles back in host memory when it stops"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -145,6 +174,9 @@ def main():
     ap.add_argument('--split-candidates', action='store_true',
                     help="strong scaling (SURVEY §8e, optional): ONE frame, its candidates split over the ranks, all-gather of "
                          "(best error, best index) and a global argmin; default is one frame per rank (weak scaling)")
+    ap.add_argument('--no-end-to-end', action='store_true',
+                    help="skip the end-to-end figure (N = 1 only, after the timed region): 256 synthetic 640x480 frames through "
+                         "Predictor.run_many — preparation, upload, lookup and every stage in lockstep batches")
     ap.add_argument('--backend', default='nccl', help="'nccl' (RCCL over xGMI); 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
@@ -346,6 +378,8 @@ def main():
                          "other_kernels_ms": {"fk_mvp+bounds": kern['fk'], "finalize+argmin": kern['finalize'],
                                               "pass_total": kern['total']}},
         }
+        if not args.no_end_to_end and world == 1 and args.workload == 'cfg1':
+            out["end_to_end"] = end_to_end(device)
         if not args.no_cpu_baseline and world == 1:           # reported at N=1 only
             gpu_err = e.download(want_err=True)[0]                 # errors of the last timed pass, outside the timed region
             out["cpu_baseline"] = cpu_baseline(robot, PV, W, H, ZNEAR, ZFAR, cand, tq, min(args.cpu_sample, C), gpu_err, loss, flags)

@@ -51,7 +51,7 @@ if stats and 'GRBM_GUI_ACTIVE' in summary:
     for r in csv.DictReader(open(stats[0])):
         if 'raster_queue_kernel<0, 0' in r['Name']:
             clock_grbm = summary['GRBM_GUI_ACTIVE']['avg_per_launch'] / 8.0 / float(r['AverageNs'])
-json.dump({'build_id': BUILD_ID, 'clock_ghz_grbm': clock_grbm, 'kernel': 'raster_queue_kernel<DEPTH,SCORE> (the scoring launch of large batches; raster_score_kernel<DEPTH,SCORE> before the queue)', 'command': 'bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-unshared',
+json.dump({'build_id': BUILD_ID, 'clock_ghz_grbm': clock_grbm, 'kernel': 'raster_queue_kernel<DEPTH,SCORE> (the scoring launch of large batches; raster_score_kernel<DEPTH,SCORE> before the queue)', 'command': 'bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-unshared --no-end-to-end',
            'counters': summary}, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
 if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
     fetch_kb, write_kb = summary['FETCH_SIZE']['avg_per_launch'], summary['WRITE_SIZE']['avg_per_launch']
