@@ -252,7 +252,7 @@ extern "C" int rope_create(rope_ctx **out, int device)
     if (const char *e = std::getenv("ROPE_STRATEGY")) c->strategy = std::atoi(e) & 63;                     // tuning aid: rope_set_strategy's bits
     if (const char *e = std::getenv("ROPE_SPLIT_CAP")) c->split_cap = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN")) c->split_min = std::max(1, std::min(64, std::atoi(e)));
-    if (const char *e = std::getenv("ROPE_GEO_ROWS")) c->geo_rows = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("ROPE_GEO_ROWS")) c->geo_rows = std::max(0, std::min(256, std::atoi(e)));     // d_touched holds 256 rows
     if (const char *e = std::getenv("ROPE_LAYER_MIN_WG")) c->layer_min_wg = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ROPE_SPLIT_MIN_MANY")) c->split_min_many = std::max(1, std::min(64, std::atoi(e)));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1102,6 +1102,10 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
             sa.cand_q = c->cand_dev; sa.joint_fixed = c->d_joint_fixed; sa.joint_axes = c->d_joint_axes; sa.PV = c->d_PV;
             sa.sums = c->d_sums;
             sa.touched = c->d_touched;
+            if (c->pass_id == 0x7FFFFFFF) {                 // the stamp wraps after 2^31 passes: start over on a clean array
+                HIP_TRY(c, hipMemsetAsync(c->d_touched, 0, c->touched_cap * sizeof(int), c->stream));
+                c->pass_id = 0;
+            }
             sa.pass_id = ++c->pass_id;
             a.touched = sa.touched; a.pass_id = sa.pass_id;
         }

@@ -809,7 +809,10 @@ class BatchAheadSegmenter:
     def _work(self, frames, keys):
         try:
             groups = [frames[i:i + self._batch] for i in range(0, len(frames), self._batch)]
-            with self._seg_lock:                          # for the whole chunk: the next group's trunk is in flight between results
+            # The lock is held for the whole announced chunk: the generator keeps the next group's trunk in flight between two
+            # results, so the network cannot be lent out in between.  A frame that was NOT announced (__call__'s fall-through)
+            # therefore waits for the chunk to finish, not for one batch — announce what you are going to ask for.
+            with self._seg_lock:
                 for n, results in enumerate(self._seg.batches(groups)):
                     i = n * self._batch
                     with self._cv:

@@ -18,7 +18,7 @@ with tempfile.TemporaryDirectory() as tmp:
     d = make_synthetic_dataset(os.path.join(tmp, 'pipe'), n, base_intrin='1280_720_color', seed=7919)
     os.chdir(tmp)
     for seg in (None, 'color', 'maskrcnn'):
-        args = argparse.Namespace(dataset=d, angs='SLU', ds_factor=8, segmenter=seg, weights=None, lookup_divisions=None, predictors=int(os.environ.get('ROPE_PREDICTORS', '4')))
+        args = argparse.Namespace(dataset=d, angs='SLU', ds_factor=8, segmenter=seg, weights=None, lookup_divisions=None, predictors=int(os.environ.get('ROPE_PREDICTORS', '1')), batch=None)
         pd.run(argparse.Namespace(**{**vars(args)}))                 # warm-up incl. construction
         t0 = time.perf_counter()
         out = pd.run(args)

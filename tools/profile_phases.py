@@ -31,7 +31,7 @@ cand = slu_grid(robot.joint_limits, grid)
 e.upload_candidates(cand)
 e.eval_resident(6, LOSS)
 e.sync()
-names = {0: 'full', 16: 'no loss pass', 32 | 16: 'no small-tri loops, no loss', 64 | 16: 'no row pass, no loss', 32 | 64 | 16: 'setup only (no S, no rows), no loss', 8: 'no pixel loop', 8 | 16: 'no pixel loop, no loss', 4 | 16: 'no triangle phase, no loss',
+names = {0: 'full', 128: 'partial last row chunk dropped (bound)', 16: 'no loss pass', 32 | 16: 'no small-tri loops, no loss', 64 | 16: 'no row pass, no loss', 32 | 64 | 16: 'setup only (no S, no rows), no loss', 8: 'no pixel loop', 8 | 16: 'no pixel loop, no loss', 4 | 16: 'no triangle phase, no loss',
          2 | 16: 'no vertex/triangle, no loss', 1: 'link cull + exit only'}
 if not hasattr(e._lib, 'rope_debug_skip'):
     raise SystemExit("needs the profiling build: python tools/build_variants.py profile && ROPE_HIP_LIB=$PWD/rope_s3d_amd/csrc/librope_hip_profile.so")
