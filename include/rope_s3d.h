@@ -143,6 +143,18 @@ int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride, const voi
 void *rope_host_alloc(size_t bytes);
 void rope_host_free(void *p);
 
+/* Host only (no context): one frame of the SEGMENTATION path, segmenter output in, target planes out: the merge of a class's
+ * instances (_reorganize_by_link, predict.py:383-395), the body mask erode7(dilate8(sum of the masks)) applied to the depth — over
+ * all detected classes for the target, over the lookup links for the lookup depth (predict.py:419-438; cv2's box kernels with their
+ * default anchors) — the depth's down-sampling (predict.py:378-381), the flags and the packing of _load_target (predict.py:397-413).
+ *   depth    H0 x W0 float32 (kind 1) / float64 (kind 2), rows depth_stride bytes apart;  f: 1 or even
+ *   masks    (H0/f) x (W0/f) x K bytes, non-zero = inside instance k (the segmenter's `masks`);  link_of: K link indices
+ *            (class id - 1), -1 for an instance that is none of the rendered links (it still widens the body mask)
+ *   out      tq, lookup_f32, flags as rope_set_target takes them; tgt_depth float64 (the masked depth) or NULL */
+int rope_prepare_segmented(const void *depth, int depth_kind, int64_t depth_stride, int H0, int W0, int f, const uint8_t *masks, int K,
+                           const int32_t *link_of, int n_links, int n_lookup_links, uint64_t *tq, float *lookup_f32, double *tgt_depth,
+                           uint8_t *flags);
+
 /* Candidate joint vectors (C x 6 doubles) into HBM; they stay resident until replaced. */
 int rope_candidates_upload(rope_ctx *ctx, const double *cand, int C);
 

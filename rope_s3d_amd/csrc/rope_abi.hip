@@ -764,6 +764,109 @@ extern "C" int rope_crop_divisions(int64_t n_pixels, int num_links, int32_t *div
     return ROPE_OK;
 }
 
+// cv2.dilate / cv2.erode of a binary image with a ones(k, k) kernel, default anchor (k / 2, k / 2), a border that never wins
+// (predict.py:428,437): separable, rows then columns; `grow` true: a pixel is set when any pixel of its window is (outside counts
+// as clear), false: when all are (outside counts as set)
+static void box_morph(const uint8_t *src, uint8_t *dst, uint8_t *tmp, int H, int W, int k, bool grow)
+{
+    const int a = k / 2, b = k - 1 - a;                  // the window of x reaches from x - a to x + b
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int lo = x - a < 0 ? 0 : x - a, hi = x + b > W - 1 ? W - 1 : x + b;
+            uint8_t v = grow ? 0 : 1;
+            for (int i = lo; i <= hi; i++) v = grow ? (uint8_t)(v | src[(size_t)y * W + i]) : (uint8_t)(v & src[(size_t)y * W + i]);
+            tmp[(size_t)y * W + x] = v;
+        }
+    for (int y = 0; y < H; y++) {
+        const int lo = y - a < 0 ? 0 : y - a, hi = y + b > H - 1 ? H - 1 : y + b;
+        for (int x = 0; x < W; x++) {
+            uint8_t v = grow ? 0 : 1;
+            for (int i = lo; i <= hi; i++) v = grow ? (uint8_t)(v | tmp[(size_t)i * W + x]) : (uint8_t)(v & tmp[(size_t)i * W + x]);
+            dst[(size_t)y * W + x] = v;
+        }
+    }
+}
+
+// Host only: one frame of the SEGMENTATION path from the segmenter's instance masks to what rope_set_target(s) takes — the merge of
+// a class's instances (_reorganize_by_link, predict.py:383-395), the body mask erode7(dilate8(sum of the masks)) that zeroes the
+// depth outside the robot, once over all classes and once over the lookup links (predict.py:419-438), the depth's own
+// down-sampling (predict.py:378-381), the per-link flags and the packing of _load_target (predict.py:397-413).
+//   masks     H x W x K bytes (non-zero = inside instance k), as the segmenter returns them;  link_of: K link indices (0..n_links-1),
+//             or -1 for an instance of a class that is not one of the rendered links (it still counts for the body mask)
+extern "C" int rope_prepare_segmented(const void *depth, int depth_kind, int64_t depth_stride, int H0, int W0, int f, const uint8_t *masks,
+                                      int K, const int32_t *link_of, int n_links, int n_lookup_links, uint64_t *tq, float *lookup_f32,
+                                      double *tgt_depth, uint8_t *flags)
+{
+    if (!depth || (K > 0 && (!masks || !link_of)) || !tq || !lookup_f32 || !flags || K < 0) return ROPE_E_ARG;
+    if (H0 < 1 || W0 < 1 || f < 1 || (f > 1 && (f & 1)) || H0 % f || W0 % f || (depth_kind != 1 && depth_kind != 2)) return ROPE_E_ARG;
+    if (n_links < 1 || n_links > ROPE_MAX_LINKS || n_lookup_links < 0 || n_lookup_links > n_links) return ROPE_E_ARG;
+    for (int k = 0; k < K; k++)
+        if (link_of[k] < -1 || link_of[k] >= n_links) return ROPE_E_ARG;
+    const int H = H0 / f, W = W0 / f, a = f / 2 - 1, b = f / 2;
+    const size_t n = (size_t)H * W;
+    std::vector<uint8_t> bits(n, 0), any(n, 0), look(n, 0), body(n), body_look(n), t1(n), t2(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *m = masks + i * (size_t)K;
+        for (int k = 0; k < K; k++)
+            if (m[k]) {
+                any[i] = 1;
+                if (link_of[k] >= 0) {
+                    bits[i] |= (uint8_t)(1u << link_of[k]);
+                    if (link_of[k] < n_lookup_links) look[i] = 1;
+                }
+            }
+    }
+    box_morph(any.data(), t1.data(), t2.data(), H, W, 8, true);
+    box_morph(t1.data(), body.data(), t2.data(), H, W, 7, false);
+    box_morph(look.data(), t1.data(), t2.data(), H, W, 8, true);
+    box_morph(t1.data(), body_look.data(), t2.data(), H, W, 7, false);
+    const double Q32 = 4294967296.0, top = 549755813887.0;
+    int64_t n_mask[ROPE_MAX_LINKS] = {}, n_depth[ROPE_MAX_LINKS] = {};
+    bool present[ROPE_MAX_LINKS] = {};
+    for (int k = 0; k < K; k++)
+        if (link_of[k] >= 0) present[link_of[k]] = true;             // a class that was detected has a mask, however empty (predict.py:408-413)
+    for (int y = 0; y < H; y++) {
+        const int ya = f > 1 ? y * f + a : y, yb = f > 1 ? y * f + b : y;
+        const char *d0 = (const char *)depth + (int64_t)ya * depth_stride, *d1 = (const char *)depth + (int64_t)yb * depth_stride;
+        for (int x = 0; x < W; x++) {
+            const size_t xa = f > 1 ? (size_t)(x * f + a) : (size_t)x, xb = f > 1 ? (size_t)(x * f + b) : (size_t)x, o = (size_t)y * W + x;
+            double d;
+            if (f > 1) {
+                if (depth_kind == 1) {
+                    const float *p0 = (const float *)d0, *p1 = (const float *)d1;
+                    const float tp = p0[xa] * 0.5f + p0[xb] * 0.5f, bt = p1[xa] * 0.5f + p1[xb] * 0.5f;
+                    d = (double)(tp * 0.5f + bt * 0.5f);
+                } else {
+                    const double *p0 = (const double *)d0, *p1 = (const double *)d1;
+                    const double tp = p0[xa] * 0.5 + p0[xb] * 0.5, bt = p1[xa] * 0.5 + p1[xb] * 0.5;
+                    d = tp * 0.5 + bt * 0.5;
+                }
+            } else {
+                d = depth_kind == 1 ? (double)((const float *)d0)[xa] : ((const double *)d0)[xa];
+            }
+            d = d * (body[o] ? 1.0 : 0.0);                           // target_depth *= body (predict.py:429)
+            const double dl = d * (body_look[o] ? 1.0 : 0.0);        // lookup_depth = the copy, *= the lookup links' body (predict.py:432-438)
+            for (int l = 0; l < n_links; l++)
+                if ((bits[o] >> l) & 1) {
+                    n_mask[l]++;
+                    if (d != 0.0) n_depth[l]++;
+                }
+            if (tgt_depth) tgt_depth[o] = d;
+            lookup_f32[o] = (float)dl;
+            double q = (std::isfinite(d) && d > 0.0) ? std::nearbyint(d * Q32) : 0.0;
+            q = q < top ? q : top;
+            tq[o] = (uint64_t)q | ((uint64_t)bits[o] << 40);
+        }
+    }
+    std::memset(flags, 0, 8);
+    for (int l = 0; l < n_links; l++)
+        if (present[l]) {
+            flags[l] |= 1;
+            if ((double)n_depth[l] > 0.05 * (double)n_mask[l]) flags[l] |= 2;
+        }
+    return ROPE_OK;
+}
+
 // Can a vertex of the robot get behind the near plane of camera PV (P·V, row-major doubles)?  z + w is affine in the world
 // position; over the ball of radius `reach` about the base origin it is at least its value at the origin minus |gradient|
 // times the radius.  Conservative with a centimetre to spare: "no" means the kernels without the clipping code draw every

@@ -24,7 +24,8 @@ ABI_SYMBOLS = (
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
     'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
     'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
-    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free', 'rope_build_id', 'rope_camera_matrix', 'rope_lookup_grid', 'rope_crop_divisions')
+    'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free', 'rope_build_id', 'rope_camera_matrix', 'rope_lookup_grid', 'rope_crop_divisions',
+    'rope_prepare_segmented')
 
 
 STAGE_LOOKUP, STAGE_DESCENT, STAGE_SFLIP, STAGE_ISWEEP, STAGE_TSWEEP = 0, 1, 2, 3, 4
@@ -133,6 +134,7 @@ def load_library(path: str = None):
     lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
     lib.rope_camera_matrix.argtypes = [vp, dbl, dbl, dbl, dbl, i32, i32, dbl, dbl, vp]
     lib.rope_crop_divisions.argtypes = [C.c_int64, i32, vp]
+    lib.rope_prepare_segmented.argtypes = [vp, i32, C.c_int64, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp]
     lib.rope_lookup_grid.argtypes = [vp, vp, vp, C.c_int64]
     lib.rope_lookup_grid.restype = C.c_int64
     lib.rope_build_id.argtypes = []
@@ -208,6 +210,28 @@ def prepare_synthetic(color: np.ndarray, depth: np.ndarray, f: int, link_blue, n
     lb = np.ascontiguousarray(link_blue, np.int32)
     rc = load_library().rope_prepare_synthetic(C.c_void_p(color.ctypes.data), color.strides[0], C.c_void_p(depth.ctypes.data), kind, depth.strides[0],
                                                H0, W0, int(f), _p(lb), len(lb), int(n_lookup_links), _p(tq), _p(lookup_f32), _p(tgt_depth), _p(flags))
+    return rc == 0
+
+
+def prepare_segmented(depth: np.ndarray, f: int, masks: np.ndarray, link_of, n_links: int, n_lookup_links: int, tq: np.ndarray,
+                      lookup_f32: np.ndarray, flags: np.ndarray, tgt_depth: np.ndarray = None) -> bool:
+    """rope_prepare_segmented: one frame of the segmentation path (instance masks (H, W, K) bool + the link of every instance) into
+    the given output arrays.  False when the layout is not one the library takes."""
+    kind = {np.dtype(np.float32): 1, np.dtype(np.float64): 2}.get(depth.dtype)
+    if kind is None or depth.ndim != 2 or depth.strides[1] != depth.itemsize or depth.strides[0] < 0:
+        return False
+    H0, W0 = depth.shape
+    if f < 1 or (f > 1 and f % 2) or H0 % f or W0 % f:
+        return False
+    m = np.ascontiguousarray(masks).view(np.uint8) if masks.dtype == bool else np.ascontiguousarray(masks, np.uint8)
+    if m.ndim != 3 or m.shape[:2] != (H0 // f, W0 // f):
+        return False
+    lo = np.ascontiguousarray(link_of, np.int32)
+    if len(lo) != m.shape[2]:
+        return False
+    assert tq.shape == (H0 // f, W0 // f) == lookup_f32.shape and tq.flags.c_contiguous and lookup_f32.flags.c_contiguous and flags.size >= 8
+    rc = load_library().rope_prepare_segmented(C.c_void_p(depth.ctypes.data), kind, depth.strides[0], H0, W0, int(f), _p(m), m.shape[2], _p(lo),
+                                               int(n_links), int(n_lookup_links), _p(tq), _p(lookup_f32), _p(tgt_depth), _p(flags))
     return rc == 0
 
 

@@ -18,7 +18,7 @@ from ..config import Paths
 from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, LOOKUP_JOINTS, LOOKUP_NUM_RENDERED
 from ..crop import Crop
 from ..engine import (LOSS_FULL, LOSS_LOOKUP, LOSS_TSWEEP, STAGE_DESCENT, STAGE_ISWEEP, STAGE_LOOKUP, STAGE_SFLIP, STAGE_TSWEEP, StageDesc,
-                      pack_target, prepare_synthetic)
+                      pack_target, prepare_segmented, prepare_synthetic)
 from ..imgproc import dilate, erode, resize_linear
 from ..projection import Intrinsics
 from ..simulation.lookup import RobotLookupManager
@@ -332,12 +332,38 @@ class Predictor:
             return None
         return PreparedTarget(tgt_depth, lookup_f32, None, tq, flags, None)
 
+    def _prepare_segmented_native(self, target_color, target_depth, tq=None, lookup_f32=None, flags=None, tgt_depth=None, want_depth=True):
+        """The segmentation path's prepare() with everything after the segmenter as ONE pass in the library (rope_prepare_segmented: the
+        instance merge, both body masks, the depth's down-sampling, flags and packing of _segmentLoad + _pack_target — same arrays).
+        None when it does not apply."""
+        if self.synthetic or self.preview or self.seg is None:
+            return None
+        depth = np.asarray(target_depth)
+        f = int(self.ds_factor)
+        if depth.ndim != 2 or depth.dtype not in (np.float32, np.float64) or f < 1 or (f > 1 and f % 2) or depth.shape[0] % f or depth.shape[1] % f:
+            return None
+        r = self.seg(self._downsample(target_color, self.ds_factor))
+        shape = (depth.shape[0] // f, depth.shape[1] // f)
+        tq = np.empty(shape, np.uint64) if tq is None else tq
+        lookup_f32 = np.empty(shape, np.float32) if lookup_f32 is None else lookup_f32
+        flags = np.zeros(8, np.uint8) if flags is None else flags
+        tgt_depth = np.empty(shape, np.float64) if (tgt_depth is None and want_depth) else tgt_depth
+        link_of = [self.link_names.index(self.classes[c]) if self.classes[c] in self.link_names else -1 for c in r['class_ids']]
+        if not prepare_segmented(depth, f, np.asarray(r['masks']), link_of, len(self.link_names), LOOKUP_NUM_RENDERED, tq, lookup_f32, flags, tgt_depth):
+            # the segmenter has been asked already (and may keep per-frame state): finish this frame the numpy way from its answer
+            d = self._downsample(depth, self.ds_factor).astype(np.float64)
+            seg = self._reorganize_by_link(r)
+            lookup_depth = segment_targets(seg, d, self.u_reader.mesh_names[:LOOKUP_NUM_RENDERED])
+            return self._pack_target(d, lookup_depth, {k: v['mask'] for k, v in seg.items()})
+        return PreparedTarget(tgt_depth, lookup_f32, None, tq, flags, None)
+
     def prepare(self, target_color, target_depth) -> PreparedTarget:
         """The host half of run(): down-sampling, link masks (colour read-off or the segmenter), body masking and
         packing (predict.py:132-137).  Touches neither the engine nor the Predictor's state, so the next frame can
         be prepared while this one is on the GPU (run_many)."""
         if self.NATIVE_PREPARE:
-            prep = self._prepare_synthetic_native(target_color, target_depth)
+            prep = self._prepare_synthetic_native(target_color, target_depth) if self.synthetic else \
+                self._prepare_segmented_native(target_color, target_depth)
             if prep is not None:
                 return prep
         target_depth = self._downsample(np.asarray(target_depth), self.ds_factor)
@@ -414,7 +440,12 @@ class Predictor:
 
         def fill(planes, k, i):
             tq, t32, fl, ts = planes
-            prep = self._prepare_synthetic_native(target_colors[i], target_depths[i], tq[k], t32[k], fl[k], want_depth=want_ts) if self.NATIVE_PREPARE else None
+            prep = None
+            if self.NATIVE_PREPARE:
+                native = self._prepare_synthetic_native if self.synthetic else self._prepare_segmented_native
+                prep = native(target_colors[i], target_depths[i], tq[k], t32[k], fl[k], want_depth=want_ts)
+                if prep is not None and not np.shares_memory(prep.tq, tq[k]):      # finished the numpy way
+                    tq[k], t32[k], fl[k] = prep.tq, prep.lookup_f32, prep.flags
             if prep is None:
                 prep = self.prepare(target_colors[i], target_depths[i])
                 tq[k], t32[k], fl[k] = prep.tq, prep.lookup_f32, prep.flags

@@ -678,3 +678,42 @@ def test_crop_grid_from_the_library_equals_crop_py():
             assert n == len(want) and lib.rope_lookup_grid(p(lim), p(d), p(got), n) == n
             assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (size, n_links)
     assert lib.rope_crop_divisions(100, 1, p(d)) == -1 and lib.rope_crop_divisions(100, 7, p(d)) == -1
+
+
+def test_native_segmented_preparation_equals_the_numpy_steps():
+    """rope_prepare_segmented (instance merge + both body masks + depth down-sampling + flags + packing in one pass in the library)
+    against Predictor's numpy steps (_reorganize_by_link, segment_targets with imgproc.dilate / erode, _pack_target): every output
+    array bit for bit — several instances per link, an instance of the background class, a link that is not detected, holes
+    that the 8x8 / 7x7 closing fills, masks touching the image border, float32 and float64 depth, factors 1 and 4."""
+    import types
+    from rope_s3d_amd import imgproc
+    from rope_s3d_amd.engine import prepare_segmented
+    from rope_s3d_amd.prediction.predict import Predictor, segment_targets
+    names = ['base_link', 'link_1_s', 'link_2_l', 'link_3_u', 'link_4_r', 'link_5_b']
+    classes = ['BG'] + names
+    rng = np.random.default_rng(21)
+    for (H, W), f, dt in (((90, 160), 1, np.float64), ((60, 80), 4, np.float32), ((48, 64), 2, np.float64)):
+        K = 9
+        class_ids = np.array([1, 2, 2, 3, 5, 5, 6, 0, 3])                 # link_3_u (class 4) is never detected; one BG instance
+        masks = np.zeros((H, W, K), bool)
+        for k in range(K):
+            y0, x0 = rng.integers(0, H - 12), rng.integers(0, W - 12)
+            masks[y0:y0 + rng.integers(6, 30), x0:x0 + rng.integers(6, 30), k] = True
+            masks[..., k] &= rng.uniform(size=(H, W)) > 0.15                # holes
+        masks[:5, :7, 0] = True                                           # touches the border
+        depth = (rng.uniform(0.4, 2.5, (H * f, W * f)) * (rng.uniform(size=(H * f, W * f)) > .1)).astype(dt)
+        depth[3, 4] = np.nan
+        fake = types.SimpleNamespace(classes=classes, link_names=names)
+        seg = Predictor._reorganize_by_link(fake, {'class_ids': class_ids, 'scores': np.ones(K), 'masks': masks})
+        d = imgproc.resize_linear(depth, W, H).astype(np.float64)
+        with np.errstate(invalid='ignore'):
+            lookup = segment_targets(seg, d, names)
+            want = Predictor._pack_target(fake, d, lookup, {k: v['mask'] for k, v in seg.items()})
+        tq, t32, flags, tgt = np.empty((H, W), np.uint64), np.empty((H, W), np.float32), np.zeros(8, np.uint8), np.empty((H, W), np.float64)
+        link_of = [names.index(classes[c]) if classes[c] in names else -1 for c in class_ids]
+        assert prepare_segmented(depth, f, masks, link_of, 6, 6, tq, t32, flags, tgt)
+        assert np.array_equal(tq, want.tq) and np.array_equal(flags, want.flags)
+        assert np.array_equal(t32.view(np.uint32), want.lookup_f32.view(np.uint32))
+        assert np.array_equal(tgt.view(np.uint64), want.tgt_depth.view(np.uint64))
+        assert flags[3] == 0 and flags[0] & 1 and (tgt != 0).any() and (tgt == 0).any()
+    assert not prepare_segmented(depth, 3, masks, link_of, 6, 6, tq, t32, flags, None)        # odd factor
