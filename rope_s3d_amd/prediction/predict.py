@@ -89,6 +89,9 @@ def segment_targets(seg: dict, target_depth: np.ndarray, lookup_links) -> np.nda
 class Predictor:
 
     SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
+    SPECULATE_BATCH = 1     # the same for a lockstep batch of SPECULATE_BATCH_FROM frames or more: with hundreds of frames in every device
+    SPECULATE_BATCH_FROM = 16   # batch the GPU is full anyway, and the reference's own order — one joint's under/over pair at a time, 2 rows
+                            # per frame instead of 26 — renders a third of the poses (5 550 against 3 220 frames/s at the defaults)
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
     NATIVE_PREPARE = True   # synthetic path: prepare() as one pass in the library (rope_prepare_synthetic); False: the numpy steps, same arrays
     BATCH = None       # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
@@ -412,8 +415,9 @@ class Predictor:
         """run_batch on the frames' stacked target planes: (B,H,W) uint64, (B,H,W) float32, (B,8) uint8 [, (B,H,W) float32]."""
         n = len(tq)
         self.engine.set_targets(tq, lookup_f32, flags, tsweep)
+        speculate = self.SPECULATE_BATCH if n >= self.SPECULATE_BATCH_FROM else self.SPECULATE
         angles, trace, n_eval = self.engine.predict_batch(self._native_stages(), self.u_reader.joint_limits, self.camera_pose, self.min_ang_inc,
-                                                          self.lookup_angles, self.lookup_crop, self._lookup_table, self.SPECULATE)
+                                                          self.lookup_angles, self.lookup_crop, self._lookup_table, speculate)
         self.evaluations += n_eval
         self.traces = [[(type(stage).__name__, trace[f, i].copy()) for i, stage in enumerate(self.stages)] for f in range(n)]
         self.trace = self.traces[-1]

@@ -152,7 +152,9 @@ def test_predict_batch_equals_frame_by_frame_and_the_reference(do_angles, table)
         assert np.array_equal(_bits(one), _bits(got[i])), f"frame {i}"
         for (k1, a1), (k2, a2) in zip(p.trace, traces[i]):
             assert k1 == k2 and np.array_equal(_bits(a1), _bits(a2)), f"frame {i} stage {k1}"
-    assert p.evaluations == evals_batch                   # the same poses were rendered and scored
+    # a lockstep batch asks for a Descent joint's under/over pair at a time (the reference's own order), the single frame for the
+    # pairs of up to three joints at once: fewer poses rendered, the same decisions
+    assert evals_batch <= p.evaluations if n >= p.SPECULATE_BATCH_FROM else evals_batch == p.evaluations
     # run_many takes the batched path by default, in groups smaller than the sequence
     many = p.run_many(colors, depths, batch=max(2, n // 3))
     assert np.array_equal(_bits(many), _bits(got))

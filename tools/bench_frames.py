@@ -22,6 +22,9 @@ div = int(sys.argv[4]) if len(sys.argv) > 4 else None
 sp = SyntheticPredictor(DEFAULT_CAMERA_POSE, intr, ds, 'SLU', noise=False, seed=1, lookup_divisions=div)
 p = sp.predictor
 p.NATIVE = os.environ.get('ROPE_NATIVE', '1') != '0'       # 0: the Python stage loop instead of rope_predict
+if 'ROPE_SPECULATE' in os.environ:
+    p.SPECULATE = int(os.environ['ROPE_SPECULATE'])        # Descent joints evaluated as one batch (1 = the reference's two renders at a time)
+    p.SPECULATE_BATCH = p.SPECULATE
 if 'ROPE_BATCH' in os.environ:
     p.BATCH = int(os.environ['ROPE_BATCH'])                # run_many: frames in lockstep per device batch (1: frame after frame; default: by plane size)
 print(f"stage loop: {'rope_predict (C++)' if p.NATIVE else 'Python'}")
