@@ -125,9 +125,9 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None,
                       f"{dt:.2f} s wall; single thread: first {len(one)} candidates, {dt1:.2f} s"}
 
 
-def end_to_end(device, n_frames=256):
+def end_to_end(device, n_frames=512):
     """The whole prediction path at the metric's resolution on one engine context, after the timed region: n_frames synthetic
-    640x480 RGB-D frames (already in host memory, as a camera or a dataset reader hands them over) through Predictor.run_many —
+    640x480 RGB-D frames (two lockstep batches of 256: the second is prepared on worker threads while the first is on the GPU) (already in host memory, as a camera or a dataset reader hands them over) through Predictor.run_many —
     host preparation, upload, the Lookup stage (9^3 grid, the reference's size rule) and every stage of the 'SLU' list, the frames
     walking the stage list in lockstep batches (rope_predict_batch).  Poses = candidate poses rendered AND scored, lookup rows
     included.  Not `value`: an extra figure beside it."""
@@ -141,7 +141,7 @@ def end_to_end(device, n_frames=256):
         sp.renderer.setJointAngles(np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]))
         frames.append(sp.renderer.render())
     colors, depths = [c for c, _ in frames], [d for _, d in frames]
-    p.run_many(colors[:128], depths[:128])                      # warm-up: buffers of a batch's size
+    p.run_many(colors[:256], depths[:256])                      # warm-up: one full lockstep batch (its page-locked planes get allocated here)
     p.evaluations = 0
     t0 = time.perf_counter()
     got = p.run_many(colors, depths)

@@ -56,6 +56,11 @@ struct rope_ctx {
     double *h_stage = nullptr;             // pinned staging: candidates up, errors + best down
     // small batches: the finalize kernel writes errors + best straight into mapped pinned host memory (no copy command)
     static constexpr int HOST_ERR_ROWS = 256;
+    // lockstep batches (rope_eval_targets): a step's rows — 2 to 26 per frame, hundreds of frames — go up, and their errors come
+    // back, through mapped host memory as well: a pass reads every row once and writes every error once, and the three copy
+    // commands it would otherwise queue (rows, frame indices, errors: 20-30 us of stream time each between 100 us of kernels)
+    // were a fifth of the device's time in a lockstep run
+    static constexpr int TARGET_HOST_ROWS = 16384;
     double *h_err = nullptr, *d_err_host = nullptr;   // host pointer and its device alias
     // small batches: the candidates stay in mapped host memory and the FK kernel reads them from there — no copy command
     // in front of the first launch of a latency-bound chain
@@ -260,11 +265,11 @@ extern "C" int rope_create(rope_ctx **out, int device)
         delete c;
         return ROPE_E_HIP;
     }
-    if (hipHostMalloc((void **)&c->h_err, (rope_ctx::HOST_ERR_ROWS + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void **)&c->h_err, (rope_ctx::TARGET_HOST_ROWS + 2) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_err_host, c->h_err, 0) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_cand, 6 * rope_ctx::HOST_ERR_ROWS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_cand, 6 * rope_ctx::TARGET_HOST_ROWS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_cand_host, c->h_cand, 0) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_frame_of, rope_ctx::HOST_ERR_ROWS * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_frame_of, rope_ctx::TARGET_HOST_ROWS * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_frame_of_host, c->h_frame_of, 0) != hipSuccess ||
         hipMalloc((void **)&c->d_best_idx, sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&c->d_qctr, 2 * QUEUE_COUNTERS * sizeof(int)) != hipSuccess ||
@@ -935,7 +940,7 @@ static int upload_candidates(rope_ctx *c, const double *cand, int C, bool group,
     int rc = ensure_capacity(c, C);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // the staging buffer may still feed an earlier copy
-    if (C <= rope_ctx::HOST_ERR_ROWS) {            // nothing is in flight (synchronised above): the kernels of the next pass read it in place
+    if (C <= (frame_of ? rope_ctx::TARGET_HOST_ROWS : rope_ctx::HOST_ERR_ROWS)) {            // nothing is in flight (synchronised above): the kernels of the next pass read it in place
         std::memcpy(c->h_cand, cand, 6 * (size_t)C * sizeof(double));
         c->cand_dev = c->d_cand_host;
         if (frame_of) { std::memcpy(c->h_frame_of, frame_of, (size_t)C * sizeof(int32_t)); c->frame_of_dev = c->d_frame_of_host; }
@@ -1244,7 +1249,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     RopeRange fin("rope:finalize");
     if (views) return ROPE_OK;                     // per-(view, frame) sums are finalised by the caller
-    c->err_on_host = c->C <= rope_ctx::HOST_ERR_ROWS;
+    c->err_on_host = c->C <= (targets ? rope_ctx::TARGET_HOST_ROWS : rope_ctx::HOST_ERR_ROWS);
     if (targets)                                   // every row against its own frame's totals and link flags; no argmin (rows of many frames)
         HIP_TRY(c, launch_finalize_frames(c->stream, c->d_sums, c->d_tg_total[loss], c->frame_of_dev, c->d_fflags, c->C, loss, n_render, n_pix,
                                           c->err_on_host ? c->d_err_host : c->d_err));

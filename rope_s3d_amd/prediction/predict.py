@@ -95,9 +95,9 @@ class Predictor:
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
     NATIVE_PREPARE = True   # synthetic path: prepare() as one pass in the library (rope_prepare_synthetic); False: the numpy steps, same arrays
     BATCH = None       # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
-                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..256 (256 at the default
-                       # 160x90, 64 at 640x480); 1: frame after frame (rope_predict).  Same angles either way.
-    BATCH_BYTES = 256 << 20
+                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..256 (256 up to
+                       # 640x480, 97 at 1280x720); 1: frame after frame (rope_predict).  Same angles either way.
+    BATCH_BYTES = 1 << 30   # two page-locked sets of this size on the host, one on the device (288 GB of HBM: a batch is small change)
 
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,

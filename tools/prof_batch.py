@@ -41,7 +41,7 @@ for lo in range(0, n, B):
     p.engine.set_targets(tq, t32, fl)
     t_up += time.perf_counter() - t
     t = time.perf_counter()
-    _, _, ne = p.engine.predict_batch(native, lim, p.camera_pose, p.min_ang_inc, p.lookup_angles, p.lookup_crop, p._lookup_table, p.SPECULATE)
+    _, _, ne = p.engine.predict_batch(native, lim, p.camera_pose, p.min_ang_inc, p.lookup_angles, p.lookup_crop, p._lookup_table, p.SPECULATE_BATCH if B >= p.SPECULATE_BATCH_FROM else p.SPECULATE)
     t_run += time.perf_counter() - t
     p.evaluations += ne
 print(f"{p.intrinsics.width}x{p.intrinsics.height}, grid {len(p.lookup_angles)}, {n} frames, batch {B}: per frame — prepare {1e3 * t_prep / n:.3f} ms (serial), "
