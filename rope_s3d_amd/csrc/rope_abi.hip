@@ -542,18 +542,30 @@ extern "C" int rope_set_target_tsweep(rope_ctx *c, const float *t32_full)
     return ROPE_OK;
 }
 
-// Host only: float64 metres + link-mask bits -> the packed plane of rope_set_target.  nearbyint under the default
-// rounding mode is numpy's rint (round half to even).
+// numpy's rint (round half to even) of a double in [0, 2^51) without a library call: adding and taking away 2^52 leaves the
+// nearest integer, ties to even, under the default rounding mode (every step one IEEE operation: -ffp-contract=off, no fast-math).
+// Beyond 2^51 the result is only used to be clipped to 2^39 - 1.
+static inline double rint_nonneg(double x)
+{
+    double t = x + 4503599627370496.0;
+    asm volatile("" : "+x"(t));                          // the sum is rounded to a double here: the two operations stay two operations
+    return t - 4503599627370496.0;
+}
+
+// depth in metres -> Q32, as rope_pack_target documents it
+static inline uint64_t q32_of_depth(double d)
+{
+    const double Q32 = 4294967296.0, top = 549755813887.0;          // 2^32, 2^39 - 1
+    double q = (d > 0.0 && d <= 1.7976931348623157e308) ? rint_nonneg(d * Q32) : 0.0;     // NaN, inf, zero and negatives: no depth
+    q = q < top ? q : top;
+    return (uint64_t)q;
+}
+
+// Host only: float64 metres + link-mask bits -> the packed plane of rope_set_target.  Rounding is numpy's rint (round half to even).
 extern "C" int rope_pack_target(const double *depth, const uint8_t *mask_bits, int64_t n, uint64_t *out)
 {
     if (!depth || !out || n < 0) return ROPE_E_ARG;
-    const double Q32 = 4294967296.0, top = 549755813887.0;          // 2^32, 2^39 - 1
-    for (int64_t i = 0; i < n; i++) {
-        const double d = depth[i];
-        double q = (std::isfinite(d) && d > 0.0) ? std::nearbyint(d * Q32) : 0.0;
-        q = q < top ? q : top;
-        out[i] = (uint64_t)q | (mask_bits ? (uint64_t)mask_bits[i] << 40 : 0);
-    }
+    for (int64_t i = 0; i < n; i++) out[i] = q32_of_depth(depth[i]) | (mask_bits ? (uint64_t)mask_bits[i] << 40 : 0);
     return ROPE_OK;
 }
 
@@ -605,8 +617,17 @@ extern "C" int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride
     if (H0 < 1 || W0 < 1 || f < 1 || (f > 1 && (f & 1)) || H0 % f || W0 % f || (depth_kind != 1 && depth_kind != 2)) return ROPE_E_ARG;
     if (n_links < 1 || n_links > ROPE_MAX_LINKS || n_lookup_links < 0 || n_lookup_links > n_links) return ROPE_E_ARG;
     const int H = H0 / f, W = W0 / f, a = f / 2 - 1, b = f / 2;
-    const double Q32 = 4294967296.0, top = 549755813887.0;          // 2^32, 2^39 - 1
-    int64_t n_mask[ROPE_MAX_LINKS] = {}, n_depth[ROPE_MAX_LINKS] = {};
+    // what a channel-0 value says about a pixel, looked up instead of compared link by link: the links whose colour it is (two
+    // links may share one), and whether one of them is a lookup link; the counts are kept per value and folded per link at the end
+    uint8_t bits_of[256] = {}, hit_of[256] = {};
+    int64_t n_val[256] = {}, n_val_depth[256] = {};
+    for (int l = 0; l < n_links; l++)
+        if (link_blue[l] >= 0 && link_blue[l] <= 255) {
+            bits_of[link_blue[l]] |= (uint8_t)(1u << l);
+            if (l < n_lookup_links) hit_of[link_blue[l]] = 1;
+        }
+    int cur = -1;                                                  // counts are kept for the run of equal values and flushed when it ends:
+    int64_t run = 0, run_depth = 0;                                // a colour-coded frame is long runs, and a counter in memory per pixel is a chain of store-to-load stalls
     for (int y = 0; y < H; y++) {
         const int ya = f > 1 ? y * f + a : y, yb = f > 1 ? y * f + b : y;
         const uint8_t *c0 = color + (int64_t)ya * color_stride, *c1 = color + (int64_t)yb * color_stride;
@@ -633,29 +654,29 @@ extern "C" int rope_prepare_synthetic(const uint8_t *color, int64_t color_stride
                 blue = c0[3 * xa];
                 d = depth_kind == 1 ? (double)((const float *)d0)[xa] : ((const double *)d0)[xa];
             }
-            unsigned bits = 0;
-            bool hit = false;
-            for (int l = 0; l < n_links; l++)
-                if (blue == link_blue[l]) {
-                    bits |= 1u << l;
-                    n_mask[l]++;
-                    if (d != 0.0) n_depth[l]++;                    // NaN counts, as `depth != 0` does
-                    if (l < n_lookup_links) hit = true;
-                }
+            const unsigned bits = bits_of[blue];
+            if (blue != cur) {
+                if (cur >= 0) { n_val[cur] += run; n_val_depth[cur] += run_depth; }
+                cur = blue; run = 0; run_depth = 0;
+            }
+            run++;
+            run_depth += (d != 0.0);                               // NaN counts, as `depth != 0` does
             const size_t o = (size_t)y * W + x;
             if (tgt_depth) tgt_depth[o] = d;
-            lookup_f32[o] = (float)(d * (hit ? 1.0 : 0.0));        // target_depth * hit (predict.py:449-454): NaN stays NaN
-            double q = (std::isfinite(d) && d > 0.0) ? std::nearbyint(d * Q32) : 0.0;
-            q = q < top ? q : top;
-            tq[o] = (uint64_t)q | ((uint64_t)bits << 40);
+            lookup_f32[o] = (float)(d * (hit_of[blue] ? 1.0 : 0.0));     // target_depth * hit (predict.py:449-454): NaN stays NaN
+            tq[o] = q32_of_depth(d) | ((uint64_t)bits << 40);
         }
     }
+    if (cur >= 0) { n_val[cur] += run; n_val_depth[cur] += run_depth; }
     std::memset(flags, 0, 8);
-    for (int l = 0; l < n_links; l++)
-        if (n_mask[l] > 0) {                                       // np.sum(mask) > 0 (predict.py:465)
+    for (int l = 0; l < n_links; l++) {
+        if (link_blue[l] < 0 || link_blue[l] > 255) continue;
+        const int64_t n_mask = n_val[link_blue[l]], n_depth = n_val_depth[link_blue[l]];
+        if (n_mask > 0) {                                          // np.sum(mask) > 0 (predict.py:465)
             flags[l] |= 1;
-            if ((double)n_depth[l] > 0.05 * (double)n_mask[l]) flags[l] |= 2;      // predict.py:495, a fact of the target alone
+            if ((double)n_depth > 0.05 * (double)n_mask) flags[l] |= 2;      // predict.py:495, a fact of the target alone
         }
+    }
     return ROPE_OK;
 }
 
@@ -825,7 +846,6 @@ extern "C" int rope_prepare_segmented(const void *depth, int depth_kind, int64_t
     box_morph(t1.data(), body.data(), t2.data(), H, W, 7, false);
     box_morph(look.data(), t1.data(), t2.data(), H, W, 8, true);
     box_morph(t1.data(), body_look.data(), t2.data(), H, W, 7, false);
-    const double Q32 = 4294967296.0, top = 549755813887.0;
     int64_t n_mask[ROPE_MAX_LINKS] = {}, n_depth[ROPE_MAX_LINKS] = {};
     bool present[ROPE_MAX_LINKS] = {};
     for (int k = 0; k < K; k++)
@@ -858,9 +878,7 @@ extern "C" int rope_prepare_segmented(const void *depth, int depth_kind, int64_t
                 }
             if (tgt_depth) tgt_depth[o] = d;
             lookup_f32[o] = (float)dl;
-            double q = (std::isfinite(d) && d > 0.0) ? std::nearbyint(d * Q32) : 0.0;
-            q = q < top ? q : top;
-            tq[o] = (uint64_t)q | ((uint64_t)bits[o] << 40);
+            tq[o] = q32_of_depth(d) | ((uint64_t)bits[o] << 40);
         }
     }
     std::memset(flags, 0, 8);
