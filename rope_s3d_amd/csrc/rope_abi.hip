@@ -433,12 +433,17 @@ extern "C" int rope_set_robot(rope_ctx *c, const uint32_t *ml_header, int n_mesh
     HIP_TRY(c, realloc_dev(&c->d_verts, 3 * (size_t)n_ml_verts));
     HIP_TRY(c, realloc_dev(&c->d_tris, (size_t)n_ml_tris));
     HIP_TRY(c, realloc_dev(&c->d_aabb, 8 * (size_t)n_meshlets));
-    HIP_TRY(c, hipMemcpy(c->d_aabb, aabb.data(), 32 * (size_t)n_meshlets, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_header, ml_header, 32 * (size_t)n_meshlets, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_verts, ml_verts, 12 * (size_t)n_ml_verts, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_tris, ml_tris, 4 * (size_t)n_ml_tris, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_joint_fixed, joint_fixed, 72 * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_joint_axes, joint_axes, 18 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpyAsync(c->d_aabb, aabb.data(), 32 * (size_t)n_meshlets, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_header, ml_header, 32 * (size_t)n_meshlets, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_verts, ml_verts, 12 * (size_t)n_ml_verts, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_tris, ml_tris, 4 * (size_t)n_ml_tris, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_joint_fixed, joint_fixed, 72 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_joint_axes, joint_axes, 18 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // Every copy and fill of this library goes through the context's OWN stream and is waited for there: the stream is a
+    // non-blocking one, which the null stream's operations are not ordered with, and whether a null-stream hipMemset / hipMemcpy
+    // has finished when it returns is the runtime's business (round 3: a first small batch on a fresh context sometimes scored
+    // against stamps that a late hipMemset of their array had wiped)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->rp.ml_header = c->d_header;
     c->rp.ml_verts = c->d_verts;
     c->rp.ml_tris = c->d_tris;
@@ -491,7 +496,8 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
             c->empty_version[k] = 0;
         }
     }
-    HIP_TRY(c, hipMemcpy(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpyAsync(c->d_PV, PV, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::memcpy(c->h_PV, PV, sizeof c->h_PV);
     c->fp.W = W; c->fp.H = H;
     c->fp.tiles_x = tiles_x;
@@ -1222,7 +1228,7 @@ static int enqueue_eval(rope_ctx *c, int n_render, int loss, const FrameParams &
             if ((size_t)c->C * c->n_tiles > c->touched_cap) {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 HIP_TRY(c, realloc_dev(&c->d_touched, (size_t)256 * c->n_tiles));
-                HIP_TRY(c, hipMemset(c->d_touched, 0, (size_t)256 * c->n_tiles * sizeof(int)));
+                HIP_TRY(c, hipMemsetAsync(c->d_touched, 0, (size_t)256 * c->n_tiles * sizeof(int), c->stream));     // ordered with the kernels that stamp it
                 c->touched_cap = (size_t)256 * c->n_tiles;
             }
             sa.cand_q = c->cand_dev; sa.joint_fixed = c->d_joint_fixed; sa.joint_axes = c->d_joint_axes; sa.PV = c->d_PV;
@@ -1422,7 +1428,7 @@ extern "C" int rope_lookup_build(rope_ctx *c, const double *cand, int C, int n_r
     }
     if (!c->d_zero_total) {
         HIP_TRY(c, hipMalloc((void **)&c->d_zero_total, ROPE_SUM_WORDS * sizeof(uint64_t)));
-        HIP_TRY(c, hipMemset(c->d_zero_total, 0, ROPE_SUM_WORDS * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemsetAsync(c->d_zero_total, 0, ROPE_SUM_WORDS * sizeof(uint64_t), c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_table, 0, need * sizeof(float), c->stream));
     FrameParams fp = c->fp;
@@ -1732,7 +1738,7 @@ extern "C" int rope_lookup_score_targets(rope_ctx *c, int32_t *best_idx, double 
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->tg_t32c_cap = 0;
         HIP_TRY(c, realloc_dev(&c->d_tg_t32c, N * crop_px + 4));
-        HIP_TRY(c, hipMemset(c->d_tg_t32c, 0, (N * crop_px + 4) * sizeof(float)));
+        HIP_TRY(c, hipMemsetAsync(c->d_tg_t32c, 0, (N * crop_px + 4) * sizeof(float), c->stream));
         c->tg_t32c_cap = N * crop_px;
     }
     if (N * c->table_C > c->tg_scores_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->tg_scores_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_scores, N * c->table_C)); c->tg_scores_cap = N * c->table_C; }

@@ -184,3 +184,30 @@ def test_robot_mesh_entry_point_rejects_broken_meshes(scene):
     e.set_robot(rb)                                             # the context is still usable
     depth, ids = e.render(np.zeros(6), 6)
     assert (ids != 255).any()
+
+
+def test_first_small_batch_on_fresh_contexts():
+    """The very first evaluation of a context is a two-row batch (a Predictor's first SFlip): forward kinematics and boxes inside the
+    split raster's workgroups, the per-(candidate, tile) stamps of a freshly allocated array, the merged tiles of a freshly
+    allocated buffer.  Forty fresh contexts give the oracle's bits every time (round 3: once in a few suite runs a Predictor's
+    first SFlip took the other branch — every fill and copy now goes through the context's own stream)."""
+    rb = helpers.robot()
+    intr, PV = helpers.camera('640_480_color', ds=4)
+    o = helpers.make_oracle(rb, intr, PV)
+    d_ref, id_ref = o.render([0.5, 0.2, 0.9, 0, 0, 0], 6)
+    tq, t32, flags, *_ = helpers.synthetic_target(d_ref, id_ref)
+    rows = np.array([[-0.7853981633974483, -0.9948, 0.2327, 0, 0, 0], [0.7853981633974483, -0.9948, 0.2327, 0, 0, 0]])
+    want, want_sums = o.eval(rows, eng.LOSS_FULL, 4, tq, t32, None, flags, threads=2, want_sums=True)
+    for k in range(40):
+        e = eng.Engine(0)
+        e.set_robot(rb)
+        e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+        e.set_target(tq, t32, flags)
+        if k % 2:                                       # as a Predictor does it: a lookup table first
+            e.lookup_build(helpers.slu_grid(rb.joint_limits, 3), 6, [5, intr.height - 5, 5, intr.width - 5])
+            e.lookup_score()
+        err, sums, _, _ = e.eval(rows, 4, eng.LOSS_FULL, want_sums=True)
+        assert np.array_equal(sums, want_sums) and np.array_equal(err.view(np.uint64), want.view(np.uint64)), k
+        err2, sums2, _, _ = e.eval(rows[::-1], 4, eng.LOSS_FULL, want_sums=True)
+        assert np.array_equal(sums2, want_sums[::-1]), k
+        e.close()

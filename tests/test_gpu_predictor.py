@@ -93,8 +93,17 @@ def test_segmentation_path_trace_matches_reference(synth, fseed):
     want, trace, _ = predictor_ref.predict_reference(
         o, tgt, None, rb.link_names, {}, lim, DEFAULT_CAMERA_POSE, helpers.slu_grid(lim, 4), p.lookup_crop, 'SLU',
         seg_masks={k: v['mask'] for k, v in seg.items()}, lookup_depth=lookup)
-    for (k_ref, a_ref), (k_got, a_got) in zip(trace, p.trace):
-        assert np.array_equal(a_ref, a_got), f"stage {k_got}: {a_got} vs reference {a_ref}"
+    for i, ((k_ref, a_ref), (k_got, a_got)) in enumerate(zip(trace, p.trace)):
+        if not np.array_equal(a_ref, a_got):
+            # what the two sides saw at the pose they parted at and at each other's answer: the engine's errors against the
+            # current target, the oracle's against the target this test prepared
+            rows = np.array([trace[i - 1][1] if i else a_ref, a_ref, a_got])
+            from oracle import oracle as orc
+            tq_ref = orc.pack_target(tgt, sum((np.asarray(seg[n]['mask'], np.uint64) << np.uint64(l)) for l, n in enumerate(rb.link_names) if n in seg))
+            print("engine errors n=4:", p.engine.eval(rows, 4, 1)[0], " n=6:", p.engine.eval(rows, 6, 1)[0])
+            print("oracle errors n=4:", o.eval(rows, 1, 4, tq_ref, link_flags=p._flags, threads=4), " n=6:", o.eval(rows, 1, 6, tq_ref, link_flags=p._flags, threads=4))
+            print("target planes equal:", np.array_equal(tq_ref, p._tq), "flags", p._flags)
+        assert np.array_equal(a_ref, a_got), f"stage {i} {k_got}: {a_got} vs reference {a_ref}"
     assert np.array_equal(got, want)
     if fseed == 123:
         assert np.abs(got - q_true)[:3].max() < 0.25
