@@ -125,9 +125,10 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None,
                       f"{dt:.2f} s wall; single thread: first {len(one)} candidates, {dt1:.2f} s"}
 
 
-def end_to_end(device, n_frames=512):
+def end_to_end(device, n_frames=2048):
     """The whole prediction path at the metric's resolution on one engine context, after the timed region: n_frames synthetic
-    640x480 RGB-D frames (two lockstep batches of 256: the second is prepared on worker threads while the first is on the GPU) (already in host memory, as a camera or a dataset reader hands them over) through Predictor.run_many —
+    640x480 RGB-D frames (already in host memory, as a camera or a dataset reader hands them over) through Predictor.run_many: lockstep
+    batches of 512, the next batch prepared on worker threads and uploaded on the engine's second stream while one is on the GPU —
     host preparation, upload, the Lookup stage (9^3 grid, the reference's size rule) and every stage of the 'SLU' list, the frames
     walking the stage list in lockstep batches (rope_predict_batch).  Poses = candidate poses rendered AND scored, lookup rows
     included.  Not `value`: an extra figure beside it."""
@@ -141,14 +142,15 @@ def end_to_end(device, n_frames=512):
         sp.renderer.setJointAngles(np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]))
         frames.append(sp.renderer.render())
     colors, depths = [c for c, _ in frames], [d for _, d in frames]
-    p.run_many(colors[:256], depths[:256])                      # warm-up: one full lockstep batch (its page-locked planes get allocated here)
+    b = p.default_batch()
+    p.run_many(colors[:2 * b], depths[:2 * b])                  # warm-up: two full lockstep batches (both sets of page-locked planes get allocated here)
     p.evaluations = 0
     t0 = time.perf_counter()
     got = p.run_many(colors, depths)
     dt = time.perf_counter() - t0
     truth = np.array([np.random.default_rng(7919 + f).uniform(lim[:, 0], lim[:, 1]) * np.array([1, 1, 1, 0, 0, 0]) for f in range(n_frames)])
     return {"frames_per_s": n_frames / dt, "poses_per_s": p.evaluations / dt, "frames": n_frames,
-            "evaluations_per_frame": p.evaluations / n_frames, "lookup_grid": int(len(p.lookup_angles)),
+            "evaluations_per_frame": p.evaluations / n_frames, "lookup_grid": int(len(p.lookup_angles)), "lockstep_batch": b,
             "median_abs_joint_error_rad": float(np.median(np.abs(got - truth)[:, :3])),
             "workload": "640x480 / 1, 'SLU' stage list, one Predictor (one engine context), frames in lockstep batches; "
                         "frames in host memory when the clock starts, angles back in host memory when it stops"}

@@ -281,6 +281,17 @@ int rope_eval_targets(rope_ctx *ctx, const double *cand, const int32_t *frame_of
                       double *err_out);
 int rope_lookup_score_targets(rope_ctx *ctx, int32_t *best_idx, double *best_score, double *scores_out);
 
+/* The next set of targets on its way up while the resident set is being predicted (a dataset in groups of frames: the upload of
+ * group k+1 hidden behind the stages of group k).  The context holds two sets of target planes.
+ * rope_stage_targets: arguments as rope_set_targets, into the set NOT in use, on a stream of its own; returns when the copies are
+ *   enqueued (sources from rope_host_alloc; pageable sources are copied through a pinned block and the call returns when the last
+ *   chunk is enqueued).  May be called from another thread than the one evaluating on this context.  The host buffers belong to
+ *   the copy until rope_commit_targets returns.
+ * rope_commit_targets: waits for the upload and for the context's work, then makes the staged set the resident one (as if
+ *   rope_set_targets had been called with it).  ROPE_E_ARG when nothing is staged or the image size changed in between. */
+int rope_stage_targets(rope_ctx *ctx, int n_frames, const uint64_t *tq, const float *t32, const float *t32_tsweep, const uint8_t *link_flags);
+int rope_commit_targets(rope_ctx *ctx);
+
 /* rope_predict for the n_frames resident targets of rope_set_targets, in lockstep: the same stage list, limits and camera for all of
  * them (args as rope_predict; lookup_angles_live must be NULL — the table aliasing makes frames depend on their order).  A frame
  * that leaves a Descent stage early simply contributes no rows to the later batches of that stage.  Every frame's angles and trace

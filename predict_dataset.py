@@ -81,7 +81,12 @@ def run(args):
 
     lo, hi = shard_range(ds.length, rank, world)
     out = np.zeros((hi - lo, 6))
-    chunk = max(200, 2 * (getattr(args, 'batch', None) or 0))   # the reference reads ~200 frames at a time (predict_dataset.py:27-41)
+    # The reference reads ~200 frames at a time (predict_dataset.py:27-41).  Here a chunk is several lockstep batches, so that inside
+    # run_many the preparation and upload of one batch hide behind the stages of the one before; bounded by the bytes of raw
+    # frames held (two chunks: the one being predicted and the one being read).
+    batch = getattr(args, 'batch', None) or am.default_batch()
+    frame_bytes = max(1, int(np.prod(ds.og_img.shape[1:])) * ds.og_img.dtype.itemsize + int(np.prod(ds.depthmaps.shape[1:])) * ds.depthmaps.dtype.itemsize)
+    chunk = max(200, min(4 * batch, max(batch, (4 << 30) // frame_bytes)))
 
     def read(start):
         end = min(start + chunk, hi)
@@ -131,6 +136,6 @@ if __name__ == "__main__":
                         help="Predictors (engine contexts + threads) per GPU when the link masks come from the colour render; default 1: "
                              "one Predictor walking -batch frames in lockstep.")
     parser.add_argument('-batch', type=int, default=None,
-                        help="Frames that walk the stage list in lockstep (one device batch per step over all of them); default: by frame size, 16..256; 1: frame after frame.")
+                        help="Frames that walk the stage list in lockstep (one device batch per step over all of them); default: by frame size, 16..512; 1: frame after frame.")
     parser.add_argument('-weights', type=str, default=None, help="weights for -segmenter maskrcnn: the reference's trained Keras .h5 or a torch state_dict (random weights otherwise).")
     run(parser.parse_args())

@@ -162,6 +162,18 @@ struct rope_ctx {
     int tg_total_cap = 0;
     size_t tg_empty_cap = 0;
     bool tg_total_valid[4] = {false, false, false, false};
+    // rope_stage_targets / rope_commit_targets: the NEXT set of targets, uploaded on a stream of its own while the resident set is
+    // in use; committing swaps the two sets of planes
+    hipStream_t copy_stream = nullptr;
+    unsigned char *h_copy2 = nullptr;       // pinned block for pageable sources on the upload stream
+    uint64_t *s_ftq = nullptr;
+    float *s_ft32 = nullptr, *s_fts32 = nullptr;
+    LinkFlags *s_fflags = nullptr;
+    size_t s_frames_cap = 0, s_t32_cap = 0, s_fts_cap = 0;
+    int s_fflags_cap = 0;
+    int staged_n = 0, staged_W = 0, staged_H = 0;
+    std::string stage_err;                  // rope_stage_targets may run beside an evaluation: its own message
+    bool staged_t32 = false, staged_ts = false;
     int tg_crop[4][4] = {};
     int32_t *d_frame_of = nullptr, *h_frame_of = nullptr, *d_frame_of_host = nullptr;   // rows' frame indices: device copy / mapped host memory (small batches)
     int frame_of_cap = 0;
@@ -306,22 +318,28 @@ extern "C" void rope_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-static int copy_h2d_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
+// `stream` / `block`: the context's own stream and pinned block by default; rope_stage_targets passes the upload stream and a block of its own
+static int copy_h2d_on(rope_ctx *c, hipStream_t stream, unsigned char **block, void *dst, const void *src, size_t bytes)
 {
     constexpr size_t CHUNK = 8u << 20;
     if (bytes >= (64u << 10) && is_pinned_host(src)) {     // already page-locked: one copy at the link's rate, no staging; the caller synchronises
-        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
         return ROPE_OK;
     }
-    if (!c->h_copy) HIP_TRY(c, hipHostMalloc((void **)&c->h_copy, 2 * CHUNK, hipHostMallocDefault));   // two halves, alternating
+    if (!*block) HIP_TRY(c, hipHostMalloc((void **)block, 2 * CHUNK, hipHostMallocDefault));   // two halves, alternating
     int half = 0;
     for (size_t off = 0; off < bytes; off += CHUNK, half ^= 1) {
         const size_t n = std::min(CHUNK, bytes - off);
-        if (off >= 2 * CHUNK || off == 0) HIP_TRY(c, hipStreamSynchronize(c->stream));   // the half about to be overwritten is free again
-        std::memcpy(c->h_copy + half * CHUNK, static_cast<const unsigned char *>(src) + off, n);
-        HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, c->h_copy + half * CHUNK, n, hipMemcpyHostToDevice, c->stream));
+        if (off >= 2 * CHUNK || off == 0) HIP_TRY(c, hipStreamSynchronize(stream));   // the half about to be overwritten is free again
+        std::memcpy(*block + half * CHUNK, static_cast<const unsigned char *>(src) + off, n);
+        HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, *block + half * CHUNK, n, hipMemcpyHostToDevice, stream));
     }
     return ROPE_OK;
+}
+
+static int copy_h2d_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    return copy_h2d_on(c, c->stream, &c->h_copy, dst, src, bytes);
 }
 
 static int copy_d2h_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
@@ -342,11 +360,13 @@ extern "C" void rope_destroy(rope_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *ptrs[] = {c->d_header, c->d_tris, c->d_verts, c->d_joint_fixed, c->d_joint_axes, c->d_PV, c->d_tq, c->d_t32,
                     c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_tcount, c->d_toff, c->d_tused, c->d_tgoff, c->d_tgval, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_touched, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3], c->d_fts32, c->d_fflags, c->d_tg_total[0], c->d_tg_total[1], c->d_tg_total[2],
-                    c->d_tg_total[3], c->d_tg_empty, c->d_frame_of, c->d_tg_t32c, c->d_tg_ltotal, c->d_tg_scores, c->d_tg_best, c->d_t32ts};
+                    c->d_tg_total[3], c->d_tg_empty, c->d_frame_of, c->d_tg_t32c, c->d_tg_ltotal, c->d_tg_scores, c->d_tg_best, c->d_t32ts,
+                    c->s_ftq, c->s_ft32, c->s_fts32, c->s_fflags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -356,6 +376,8 @@ extern "C" void rope_destroy(rope_ctx *c)
     if (c->h_vstage) (void)hipHostFree(c->h_vstage);
     if (c->h_vsums) (void)hipHostFree(c->h_vsums);
     if (c->h_copy) (void)hipHostFree(c->h_copy);
+    if (c->h_copy2) (void)hipHostFree(c->h_copy2);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -480,6 +502,7 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
         c->have_t32ts = false;
         c->n_frames = 0;
         c->n_targets = 0;
+        c->staged_n = 0;                          // a staged set of the old size is not committed
         c->C = 0;
         c->cand_valid = c->results_valid = false;
         const size_t n = (size_t)W * H;
@@ -1627,6 +1650,21 @@ extern "C" int rope_eval_views(rope_ctx *c, const double *PV, int K, int n_rende
     return ROPE_OK;
 }
 
+// per-frame scratch of the batched prediction, sized for n_frames resident targets
+static int size_target_scratch(rope_ctx *c, int n_frames)
+{
+    if (n_frames > c->tg_total_cap) {
+        c->tg_total_cap = 0;
+        for (int k = 0; k < 4; k++) HIP_TRY(c, realloc_dev(&c->d_tg_total[k], (size_t)n_frames * ROPE_SUM_WORDS));
+        HIP_TRY(c, realloc_dev(&c->d_tg_ltotal, (size_t)n_frames * ROPE_SUM_WORDS));
+        c->tg_total_cap = n_frames;
+    }
+    const size_t empties = (size_t)n_frames * c->n_tiles * ROPE_SUM_WORDS;
+    if (empties > c->tg_empty_cap) { c->tg_empty_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_empty, empties)); c->tg_empty_cap = empties; }
+    if (n_frames > c->tg_best_cap) { c->tg_best_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_best, 2 * (size_t)n_frames)); c->tg_best_cap = n_frames; }
+    return ROPE_OK;
+}
+
 // ---- batched prediction: the targets of many frames resident at once, every row of a batch scored against its own frame's
 extern "C" int rope_set_targets(rope_ctx *c, int n_frames, const uint64_t *tq, const float *t32, const float *t32_tsweep, const uint8_t *link_flags)
 {
@@ -1655,18 +1693,84 @@ extern "C" int rope_set_targets(rope_ctx *c, int n_frames, const uint64_t *tq, c
     static_assert(sizeof(LinkFlags) == 8, "link flags travel as 8 bytes per frame");
     rc = copy_h2d_staged(c, c->d_fflags, link_flags, 8 * (size_t)n_frames);
     if (rc) return rc;
-    if (n_frames > c->tg_total_cap) {
-        c->tg_total_cap = 0;
-        for (int k = 0; k < 4; k++) HIP_TRY(c, realloc_dev(&c->d_tg_total[k], (size_t)n_frames * ROPE_SUM_WORDS));
-        HIP_TRY(c, realloc_dev(&c->d_tg_ltotal, (size_t)n_frames * ROPE_SUM_WORDS));
-        c->tg_total_cap = n_frames;
-    }
-    const size_t empties = (size_t)n_frames * c->n_tiles * ROPE_SUM_WORDS;
-    if (empties > c->tg_empty_cap) { c->tg_empty_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_empty, empties)); c->tg_empty_cap = empties; }
-    if (n_frames > c->tg_best_cap) { c->tg_best_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_best, 2 * (size_t)n_frames)); c->tg_best_cap = n_frames; }
+    rc = size_target_scratch(c, n_frames);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->targets_t32 = (t32 != nullptr);
     c->targets_ts = (t32_tsweep != nullptr);
+    for (bool &v : c->tg_total_valid) v = false;
+    for (bool &v : c->ftotal_valid) v = false;
+    c->n_targets = n_frames;
+    return ROPE_OK;
+}
+
+// The same targets as rope_set_targets, but into the context's SECOND set of planes and on a stream of its own: returns once the
+// copies are enqueued (page-locked sources, rope_host_alloc) — the resident set stays in use meanwhile, from this or another thread
+// (this call touches nothing the evaluation calls use).  The host buffers belong to the copy until rope_commit_targets returns.
+extern "C" int rope_stage_targets(rope_ctx *c, int n_frames, const uint64_t *tq, const float *t32, const float *t32_tsweep, const uint8_t *link_flags)
+{
+    if (!c) return ROPE_E_ARG;
+    // this call may run beside an evaluation on another thread: its failures are reported through the return code and a message of its own
+    auto fail = [&](int code, const char *msg) { c->stage_err = msg; return code; };
+    if (!c->have_camera) return fail(ROPE_E_ARG, "rope_stage_targets: call rope_set_camera first (image size)");
+    if (!tq || !link_flags || n_frames < 1 || n_frames > 65535) return fail(ROPE_E_ARG, "rope_stage_targets: need 1 <= n_frames <= 65535, tq and link_flags");
+    if (hipSetDevice(c->device) != hipSuccess) return fail(ROPE_E_HIP, "rope_stage_targets: hipSetDevice failed");
+    if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(ROPE_E_HIP, "rope_stage_targets: no stream");
+    if (hipStreamSynchronize(c->copy_stream) != hipSuccess) return fail(ROPE_E_HIP, "rope_stage_targets: the upload stream failed");
+    c->staged_n = 0;
+    const int W = c->fp.W, H = c->fp.H;
+    const size_t plane = (size_t)W * H, n = plane * (size_t)n_frames;
+    bool ok = true;
+    auto grow = [&](auto **p, size_t &cap, size_t want) {
+        if (want <= cap) return;
+        cap = 0;
+        if (realloc_dev(p, want) != hipSuccess) { ok = false; return; }
+        cap = want;
+    };
+    grow(&c->s_ftq, c->s_frames_cap, n);
+    if (t32) grow(&c->s_ft32, c->s_t32_cap, n);
+    if (t32_tsweep) grow(&c->s_fts32, c->s_fts_cap, n);
+    if (n_frames > c->s_fflags_cap) {
+        c->s_fflags_cap = 0;
+        if (realloc_dev(&c->s_fflags, (size_t)n_frames) == hipSuccess) c->s_fflags_cap = n_frames; else ok = false;
+    }
+    if (!ok) { (void)hipGetLastError(); return fail(ROPE_E_NOMEM, "rope_stage_targets: out of device memory"); }
+    std::string keep = c->err;                     // copy_h2d_on reports into c->err: move its message where this call's belong
+    // the few bytes of flags first: a small (or pageable) source goes through the pinned block, which waits for the stream
+    int rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_fflags, link_flags, 8 * (size_t)n_frames);
+    if (!rc) rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_ftq, tq, n * sizeof(uint64_t));
+    if (!rc && t32) rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_ft32, t32, n * sizeof(float));
+    if (!rc && t32_tsweep) rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_fts32, t32_tsweep, n * sizeof(float));
+    if (rc) { c->stage_err = c->err; c->err = keep; return rc; }
+    c->staged_t32 = (t32 != nullptr);
+    c->staged_ts = (t32_tsweep != nullptr);
+    c->staged_W = W; c->staged_H = H;
+    c->staged_n = n_frames;
+    return ROPE_OK;
+}
+
+// The staged set becomes the resident one (and the resident planes the next staging space): waits for the upload and for the
+// context's own stream, then swaps.
+extern "C" int rope_commit_targets(rope_ctx *c)
+{
+    if (!c) return ROPE_E_ARG;
+    if (c->staged_n < 1) { c->err = c->stage_err.empty() ? "rope_commit_targets: nothing staged (rope_stage_targets)" : c->stage_err; return ROPE_E_ARG; }
+    if (c->staged_W != c->fp.W || c->staged_H != c->fp.H) { c->staged_n = 0; ARG_FAIL(c, "rope_commit_targets: the image size changed since rope_stage_targets"); }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int n_frames = c->staged_n;
+    c->staged_n = 0;
+    c->n_targets = 0;
+    c->n_frames = 0;                              // d_ftq / d_ft32 are shared with the camera-pose path's frames
+    std::swap(c->d_ftq, c->s_ftq);       std::swap(c->frames_cap, c->s_frames_cap);
+    if (c->staged_t32) { std::swap(c->d_ft32, c->s_ft32);   std::swap(c->frames_t32_cap, c->s_t32_cap); }
+    if (c->staged_ts)  { std::swap(c->d_fts32, c->s_fts32); std::swap(c->fts_cap, c->s_fts_cap); }
+    std::swap(c->d_fflags, c->s_fflags); std::swap(c->fflags_cap, c->s_fflags_cap);
+    int rc = size_target_scratch(c, n_frames);
+    if (rc) return rc;
+    c->targets_t32 = c->staged_t32;
+    c->targets_ts = c->staged_ts;
     for (bool &v : c->tg_total_valid) v = false;
     for (bool &v : c->ftotal_valid) v = false;
     c->n_targets = n_frames;

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     'rope_lookup_build', 'rope_lookup_score', 'rope_render', 'rope_coverage', 'rope_debug_mvp', 'rope_profile_eval', 'rope_set_strategy',
     'rope_set_frames', 'rope_eval_views', 'rope_predict', 'rope_set_robot_mesh', 'rope_partition_mesh', 'rope_pack_target', 'rope_downsample_even',
     'rope_seg_nms', 'rope_seg_roi_align', 'rope_seg_bias_act',
-    'rope_set_target_tsweep', 'rope_set_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
+    'rope_set_target_tsweep', 'rope_set_targets', 'rope_stage_targets', 'rope_commit_targets', 'rope_eval_targets', 'rope_lookup_score_targets', 'rope_predict_batch',
     'rope_prepare_synthetic', 'rope_host_alloc', 'rope_host_free', 'rope_build_id', 'rope_camera_matrix', 'rope_lookup_grid', 'rope_crop_divisions',
     'rope_prepare_segmented')
 
@@ -129,6 +129,8 @@ def load_library(path: str = None):
     lib.rope_eval_views.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.rope_set_target_tsweep.argtypes = [vp, vp]
     lib.rope_set_targets.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.rope_stage_targets.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.rope_commit_targets.argtypes = [vp]
     lib.rope_eval_targets.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.rope_lookup_score_targets.argtypes = [vp, vp, vp, vp]
     lib.rope_predict_batch.argtypes = [vp, C.POINTER(PredictArgs), i32, vp, vp, C.POINTER(C.c_int64)]
@@ -317,9 +319,7 @@ class Engine:
         self._check(self._lib.rope_set_target_tsweep(self._ctx, _p(t32_full)), 'rope_set_target_tsweep')
 
     # -- many frames at once --------------------------------------------------------------------
-    def set_targets(self, tq: np.ndarray, t32: np.ndarray = None, link_flags: np.ndarray = None, t32_tsweep: np.ndarray = None):
-        """The targets of N frames resident at once (rope_set_targets): tq (N,H,W) uint64, t32 / t32_tsweep (N,H,W) float32 or None,
-        link_flags (N,8) uint8."""
+    def _target_planes(self, tq, t32, link_flags, t32_tsweep):
         tq = np.ascontiguousarray(tq, np.uint64)
         n = len(tq)
         if tq.shape != (n, self.H, self.W):
@@ -334,8 +334,31 @@ class Engine:
         lf = np.zeros((n, 8), np.uint8)
         if link_flags is not None:
             lf[:] = np.asarray(link_flags, np.uint8).reshape(n, 8)
-        self._check(self._lib.rope_set_targets(self._ctx, n, _p(tq), _p(planes[0]), _p(planes[1]), _p(lf)), 'rope_set_targets')
+        return n, tq, planes[0], planes[1], lf
+
+    def set_targets(self, tq: np.ndarray, t32: np.ndarray = None, link_flags: np.ndarray = None, t32_tsweep: np.ndarray = None):
+        """The targets of N frames resident at once (rope_set_targets): tq (N,H,W) uint64, t32 / t32_tsweep (N,H,W) float32 or None,
+        link_flags (N,8) uint8."""
+        n, tq, t32, ts, lf = self._target_planes(tq, t32, link_flags, t32_tsweep)
+        self._check(self._lib.rope_set_targets(self._ctx, n, _p(tq), _p(t32), _p(ts), _p(lf)), 'rope_set_targets')
         self.n_targets = n
+
+    def stage_targets(self, tq: np.ndarray, t32: np.ndarray = None, link_flags: np.ndarray = None, t32_tsweep: np.ndarray = None):
+        """set_targets into the context's second set of planes, on a stream of its own (rope_stage_targets): returns with the copies
+        on their way while the resident targets stay in use — from this thread or another.  The arrays must stay alive and
+        untouched until commit_targets() (they are kept here); page-locked ones (pinned_empty) make the copy asynchronous."""
+        n, tq, t32, ts, lf = self._target_planes(tq, t32, link_flags, t32_tsweep)
+        self._staged = (n, tq, t32, ts, lf)
+        rc = self._lib.rope_stage_targets(self._ctx, n, _p(tq), _p(t32), _p(ts), _p(lf))
+        if rc:
+            self._staged = None
+            raise RuntimeError(f"rope_stage_targets failed ({rc})")
+
+    def commit_targets(self):
+        """The staged targets become the resident ones (rope_commit_targets)."""
+        self._check(self._lib.rope_commit_targets(self._ctx), 'rope_commit_targets')
+        self.n_targets = self._staged[0] if getattr(self, '_staged', None) else 0
+        self._staged = None
 
     def eval_targets(self, cand, frame_of, n_render: int, loss: int, crop=None) -> np.ndarray:
         """Row i of `cand` scored against the resident target frame_of[i] -> errors (R,)."""

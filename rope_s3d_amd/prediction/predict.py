@@ -95,9 +95,10 @@ class Predictor:
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
     NATIVE_PREPARE = True   # synthetic path: prepare() as one pass in the library (rope_prepare_synthetic); False: the numpy steps, same arrays
     BATCH = None       # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
-                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..256 (256 up to
-                       # 640x480, 97 at 1280x720); 1: frame after frame (rope_predict).  Same angles either way.
-    BATCH_BYTES = 1 << 30   # two page-locked sets of this size on the host, one on the device (288 GB of HBM: a batch is small change)
+                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..512 (512 up to
+                       # 640x480, 194 at 1280x720); 1: frame after frame (rope_predict).  Same angles either way.
+    BATCH_BYTES = 2 << 30   # two page-locked sets of this size on the host and two on the device (288 GB of HBM: a batch is small
+                            # change).  640x480: 2 760 frames/s at 256 frames per batch, 3 280 at 512, the same at 1 024
 
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
@@ -413,8 +414,11 @@ class Predictor:
 
     def _run_planes(self, tq, lookup_f32, flags, tsweep=None) -> np.ndarray:
         """run_batch on the frames' stacked target planes: (B,H,W) uint64, (B,H,W) float32, (B,8) uint8 [, (B,H,W) float32]."""
-        n = len(tq)
         self.engine.set_targets(tq, lookup_f32, flags, tsweep)
+        return self._run_resident(len(tq))
+
+    def _run_resident(self, n: int) -> np.ndarray:
+        """The stage list over the engine's n resident targets in lockstep."""
         speculate = self.SPECULATE_BATCH if n >= self.SPECULATE_BATCH_FROM else self.SPECULATE
         angles, trace, n_eval = self.engine.predict_batch(self._native_stages(), self.u_reader.joint_limits, self.camera_pose, self.min_ang_inc,
                                                           self.lookup_angles, self.lookup_crop, self._lookup_table, speculate)
@@ -426,7 +430,8 @@ class Predictor:
     def _run_many_batched(self, target_colors, target_depths, camera_poses, batch: int) -> np.ndarray:
         """run_many in groups of up to `batch` consecutive frames under one camera pose.  Worker threads prepare a group's frames
         straight into the slots of its stacked planes (host work only: down-sampling, masks, packing — the library's one-pass form
-        where it applies) while the group before it is on the GPU."""
+        where it applies) and an uploader thread sends them to the engine's second set of planes (rope_stage_targets), both
+        while the group before it is on the GPU."""
         from concurrent.futures import ThreadPoolExecutor
         from ..utils import cpu_budget
         n = len(target_colors)
@@ -458,25 +463,46 @@ class Predictor:
 
         # the segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order
         workers = max(1, min(8, cpu_budget() - 1)) if self.synthetic else 1
-        with ThreadPoolExecutor(max_workers=workers) as pool:
+        with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as uploader:
             def submit(k):
                 lo_, hi_ = groups[k]
                 b = hi_ - lo_
-                # two sets of planes in page-locked memory, taken in turn: group k+1 is written while group k is on the GPU
+                # two sets of planes in page-locked memory, taken in turn
                 tq, t32, fl, ts = self._plane_set(k & 1, min(batch, n), H, W, want_ts)
                 planes = (tq[:b], t32[:b], fl[:b], None if ts is None else ts[:b])
                 return planes, [pool.submit(fill, planes, j, lo_ + j) for j in range(b)]
-            nxt = submit(0)
-            for k, (lo, hi) in enumerate(groups):
-                planes, jobs = nxt
+
+            def stage(filled):
+                planes, jobs = filled
                 for j in jobs:
                     j.result()
+                self.engine.stage_targets(*planes[:3], planes[3])
+
+            # Group k's stages run on the GPU while group k+1's planes go up on the engine's upload stream (as soon as its frames are
+            # prepared: the uploader thread waits for them) and the workers write group k+2 into the host planes group k has left.
+            filled = {0: submit(0)}
+            staging = uploader.submit(stage, filled[0])
+            if len(groups) > 1:
+                filled[1] = submit(1)
+            for k, (lo, hi) in enumerate(groups):
+                staging.result()
+                self.engine.commit_targets()            # group k resident; its host planes are free again
+                del filled[k]
+                if k + 2 < len(groups):
+                    filled[k + 2] = submit(k + 2)
                 if k + 1 < len(groups):
-                    nxt = submit(k + 1)
+                    staging = uploader.submit(stage, filled[k + 1])
                 if camera_poses is not None and np.any(np.asarray(camera_poses[lo]) != self.camera_pose):
                     self.changeCameraPose(camera_poses[lo])
-                out[lo:hi] = self._run_planes(*planes)
+                out[lo:hi] = self._run_resident(hi - lo)
         return out
+
+    def default_batch(self) -> int:
+        """Frames per lockstep batch when run_many is not told: BATCH, or what fits BATCH_BYTES of target planes (12 bytes per
+        pixel and frame: uint64 + float32)."""
+        if self.BATCH is not None:
+            return int(self.BATCH)
+        return int(min(512, max(16, self.BATCH_BYTES // (12 * self.intrinsics.width * self.intrinsics.height))))
 
     def run_many(self, target_colors, target_depths, camera_poses=None, prefetch: bool = True, batch: int = None) -> np.ndarray:
         """run() over a sequence of frames -> (N, 6).  By default BATCH frames at a time walk the stage list in lockstep
@@ -487,9 +513,7 @@ class Predictor:
         out = np.zeros((n, 6))
         if n == 0:
             return out
-        batch = self.BATCH if batch is None else int(batch)
-        if batch is None:                              # 12 bytes of target planes per pixel and frame (uint64 + float32)
-            batch = int(min(256, max(16, self.BATCH_BYTES // (12 * self.intrinsics.width * self.intrinsics.height))))
+        batch = self.default_batch() if batch is None else int(batch)
         self._setStages()
         if batch > 1 and n > 1 and self._batch_ok():
             return self._run_many_batched(target_colors, target_depths, camera_poses, batch)

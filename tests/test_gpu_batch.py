@@ -94,6 +94,58 @@ def test_eval_targets_refuses_bad_input(scene):
         e.eval_targets(np.zeros((2, 6)), [0, 0], 6, eng.LOSS_FULL)
 
 
+def test_staged_targets_go_up_beside_the_resident_ones(scene):
+    """rope_stage_targets / rope_commit_targets: the second set of planes.  While a set is staged the resident one still answers;
+    after the commit the staged one does, with the bits rope_set_targets gives; sets of different sizes alternate."""
+    e, rb, intr, frames = scene
+    lim = rb.joint_limits
+    rng = np.random.default_rng(99)
+    cand = rng.uniform(lim[:, 0], lim[:, 1], (12, 6))
+    sets = [[0, 1, 2], [3, 4], [4, 3, 2, 1, 0], [2]]
+
+    def planes(idx, pinned):
+        arrs = (np.stack([frames[i]['tq'] for i in idx]), np.stack([frames[i]['t32'] for i in idx]), np.stack([frames[i]['flags'] for i in idx]),
+                np.stack([frames[i]['full'] for i in idx]))
+        if pinned:
+            out = []
+            for a in arrs:
+                b = eng.pinned_empty(a.shape, a.dtype)
+                b[...] = a
+                out.append(b)
+            arrs = tuple(out)
+        return arrs
+
+    def expect(idx, loss):
+        e.set_targets(*planes(idx, False))
+        fo = np.arange(len(cand)) % len(idx)
+        return fo, e.eval_targets(cand, fo, 6, loss)
+
+    want = {(k, loss): expect(idx, loss) for k, idx in enumerate(sets) for loss in (eng.LOSS_FULL, eng.LOSS_TSWEEP)}
+    with pytest.raises(eng.EngineError):
+        e.commit_targets()                                   # nothing staged
+    e.set_targets(*planes(sets[0], False))
+    for k in range(1, len(sets)):
+        e.stage_targets(*planes(sets[k], pinned=(k % 2 == 1)))
+        for loss in (eng.LOSS_FULL, eng.LOSS_TSWEEP):        # the resident set is untouched by the upload
+            fo, err = want[(k - 1, loss)]
+            assert np.array_equal(_bits(e.eval_targets(cand, fo, 6, loss)), _bits(err)), (k, loss)
+        e.commit_targets()
+        assert e.n_targets == len(sets[k])
+        for loss in (eng.LOSS_FULL, eng.LOSS_TSWEEP):
+            fo, err = want[(k, loss)]
+            assert np.array_equal(_bits(e.eval_targets(cand, fo, 6, loss)), _bits(err)), (k, loss)
+    # a change of image size between staging and committing is refused, and the context keeps working
+    e.stage_targets(*planes(sets[1], True))
+    intr2, PV2 = helpers.camera('640_480_color', ds=4)
+    e.set_camera(PV2, intr2.width, intr2.height, ZNEAR, ZFAR)
+    with pytest.raises(eng.EngineError):
+        e.commit_targets()
+    _, PV = helpers.camera('640_480_color', ds=2)
+    e.set_camera(PV, intr.width, intr.height, ZNEAR, ZFAR)
+    fo, err = expect(sets[0], eng.LOSS_FULL)
+    assert np.array_equal(_bits(err), _bits(want[(0, eng.LOSS_FULL)][1]))
+
+
 def test_lookup_score_targets_equals_per_frame(scene):
     e, rb, intr, frames = scene
     grid = helpers.slu_grid(rb.joint_limits, 6)
