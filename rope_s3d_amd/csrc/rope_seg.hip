@@ -57,61 +57,70 @@ nms_mask_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ gr
     mask[(base + row) * words + cb] = bits;
 }
 
-__global__ void __launch_bounds__(64)
+// One workgroup of 16 waves per set.  Block after block of 64 boxes: wave 0 settles the block from its own 64 x 64 bits (a chain
+// of dependent steps, one per kept box), then every wave takes some of the kept boxes' rows and ORs them into the later blocks'
+// "removed" words in LDS — the rows of a block are all in flight at once (a single wave walking them, four loads at a time, spent
+// most of the launch waiting: 0.51 ms for 8 x 6000 boxes).
+constexpr int NMS_SCAN_THREADS = 1024;
+
+__global__ void __launch_bounds__(NMS_SCAN_THREADS)
 nms_scan_kernel(const unsigned long long *__restrict__ mask, const uint8_t *__restrict__ valid, int n, int words, int limit,
                 uint8_t *__restrict__ keep)
 {
     extern __shared__ unsigned long long s_removed[];       // `words` words + 64 for the current block's own bits
     unsigned long long *const s_sub = s_removed + words;
     __shared__ int s_rows[64];                                // rows (within the block) of the boxes it kept
-    const int set = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned long long s_keepbits;
+    __shared__ int s_kept;
+    const int set = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int N_WAVES = NMS_SCAN_THREADS / 64;
     const size_t base = (size_t)set * n;
     // padding and the bits past n start out "removed": never kept, never suppressing
-    for (int w = lane; w < words; w += 64) {
-        unsigned long long r = 0;
-        for (int j = 0; j < 64; j++) {
-            const int i = w * 64 + j;
-            if (i >= n || (valid && !valid[base + i])) r |= 1ull << j;
-        }
-        s_removed[w] = r;
+    for (int i0 = wave * 64; i0 < words * 64; i0 += NMS_SCAN_THREADS) {
+        const int i = i0 + lane;
+        const unsigned long long r = __ballot(i >= n || (valid && !valid[base + i]));
+        if (lane == 0) s_removed[i0 >> 6] = r;
     }
+    if (tid == 0) s_kept = 0;
     __syncthreads();
-    int kept = 0;
-    unsigned long long own = lane < n ? mask[(base + lane) * words] : 0ull;     // this lane's row of the block's own 64 x 64 bits
+    unsigned long long own = (wave == 0 && lane < n) ? mask[(base + lane) * words] : 0ull;     // wave 0: this lane's row of the block's own 64 x 64 bits
     for (int blk = 0; blk < words; blk++) {
         const int row = blk * 64 + lane;
-        unsigned long long keepbits = 0;
-        if (kept < limit) {
+        if (wave == 0) {
             s_sub[lane] = own;
             // the next block's own bits depend on nothing here: fetched while this block is settled
             own = (blk + 1 < words && row + 64 < n) ? mask[(base + row + 64) * words + blk + 1] : 0ull;
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // the block's own bits settle it: the first box still standing is kept and strikes the later ones it overlaps
-            unsigned long long standing = ~s_removed[blk];
+            int kept = s_kept;
+            unsigned long long keepbits = 0, standing = ~s_removed[blk];
             while (standing && kept < limit) {
                 const int t = __builtin_ctzll(standing);
                 keepbits |= 1ull << t;
                 standing &= ~(s_sub[t] | (1ull << t));        // row t only has bits above t
                 kept++;
             }
-            __syncthreads();
+            if (row < n) keep[base + row] = (uint8_t)((keepbits >> lane) & 1ull);
+            if ((keepbits >> lane) & 1ull) s_rows[__popcll(keepbits & ((1ull << lane) - 1ull))] = lane;
+            if (lane == 0) { s_keepbits = keepbits; s_kept = kept; }
         }
-        if (row < n) keep[base + row] = (uint8_t)((keepbits >> lane) & 1ull);
-        if (kept >= limit || blk + 1 == words) continue;  // (the remaining blocks only write zeros)
-        // rows of the kept boxes into the later blocks' words
-        if ((keepbits >> lane) & 1ull) s_rows[__popcll(keepbits & ((1ull << lane) - 1ull))] = lane;
         __syncthreads();
-        const int n_kept = __popcll(keepbits);
-        for (int w = blk + 1 + lane; w < words; w += 64) {
-            const unsigned long long *const m = mask + (base + blk * 64) * words + w;
-            unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-            int i = 0;
-            for (; i + 4 <= n_kept; i += 4) {               // four loads in flight: the rows are independent
-                r0 |= m[(size_t)s_rows[i] * words]; r1 |= m[(size_t)s_rows[i + 1] * words];
-                r2 |= m[(size_t)s_rows[i + 2] * words]; r3 |= m[(size_t)s_rows[i + 3] * words];
+        const int kept = s_kept;
+        if (kept >= limit) {                                  // the remaining blocks only hold zeros
+            for (size_t i = (size_t)(blk + 1) * 64 + tid; i < (size_t)n; i += NMS_SCAN_THREADS) keep[base + i] = 0;
+            return;
+        }
+        if (blk + 1 == words) return;
+        // rows of the kept boxes into the later blocks' words
+        const int n_kept = __popcll(s_keepbits);
+        for (int i = wave; i < n_kept; i += N_WAVES) {
+            const unsigned long long *const m = mask + (base + blk * 64 + s_rows[i]) * words;
+            for (int w = blk + 1 + lane; w < words; w += 64) {
+                const unsigned long long bits = m[w];
+                if (bits) atomicOr(&s_removed[w], bits);
             }
-            for (; i < n_kept; i++) r0 |= m[(size_t)s_rows[i] * words];
-            s_removed[w] |= (r0 | r1) | (r2 | r3);
         }
         __syncthreads();
     }
@@ -250,7 +259,7 @@ extern "C" int rope_seg_nms(const float *boxes, const int32_t *groups, const uin
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, n_sets), dim3(64), 0, st, reinterpret_cast<const float4 *>(boxes), groups, n,
                        words, iou_thr, reinterpret_cast<unsigned long long *>(scratch));
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_sets), dim3(64), (size_t)(words + 64) * 8, st,
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_sets), dim3(NMS_SCAN_THREADS), (size_t)(words + 64) * 8, st,
                        reinterpret_cast<const unsigned long long *>(scratch), valid, n, words, limit, keep);
     return hipGetLastError() == hipSuccess ? ROPE_OK : ROPE_E_HIP;
 }
