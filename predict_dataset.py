@@ -38,6 +38,8 @@ def run(args):
         else:
             dist.init_process_group(backend)
 
+    import time
+    t_begin = time.perf_counter()
     from rope_s3d_amd.data.dataset import open_dataset
     ds = open_dataset(args.dataset, gpu)                 # a stored set, or 'synthetic:<frames>[:<seed>[:<preset>]]' rendered as it is read
     kwargs = {}
@@ -81,6 +83,7 @@ def run(args):
 
     lo, hi = shard_range(ds.length, rank, world)
     out = np.zeros((hi - lo, 6))
+    t_ready = time.perf_counter()
     # The reference reads ~200 frames at a time (predict_dataset.py:27-41).  Here a chunk is several lockstep batches, so that inside
     # run_many the preparation and upload of one batch hide behind the stages of the one before; bounded by the bytes of raw
     # frames held (two chunks: the one being predicted and the one being read).
@@ -110,6 +113,10 @@ def run(args):
         else:
             out[start - lo:end - lo] = am.run_many(og_imgs, dms, cam_poses, batch=getattr(args, 'batch', None))
     reader.shutdown()
+    if rank == 0 and os.environ.get('ROPE_TIMING'):
+        t_end = time.perf_counter()
+        print(f"rank 0: set-up {t_ready - t_begin:.2f} s (data set, segmenter, Predictor, lookup table), {hi - lo} frames in {t_end - t_ready:.2f} s = "
+              f"{(hi - lo) / max(t_end - t_ready, 1e-9):.1f} frames/s")
     full = gather_rows(out, ds.length, device=device, single_rank_too=use_dist)
     if rank == 0:
         if use_dist:

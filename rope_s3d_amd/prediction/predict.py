@@ -461,8 +461,9 @@ class Predictor:
             if ts is not None:
                 ts[k] = prep.tgt_depth
 
-        # the segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order
-        workers = max(1, min(8, cpu_budget() - 1)) if self.synthetic else 1
+        # a segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order,
+        # unless it says it keeps no state (`stateless`)
+        workers = max(1, min(8, cpu_budget() - 1)) if (self.synthetic or getattr(self.seg, 'stateless', False)) else 1
         with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as uploader:
             def submit(k):
                 lo_, hi_ = groups[k]

@@ -17,6 +17,8 @@ from .constants import DEFAULT_RENDER_COLORS
 
 class ColorSegmenter:
 
+    stateless = True            # frames may be handed over from several threads and in any order (Predictor.run_many's workers)
+
     def __init__(self, class_names, color_dict=None, split_instances: bool = False):
         """class_names: ["BG", link names...] as Predictor.classes; color_dict: name -> [b,g,r] (defaults to
         DEFAULT_RENDER_COLORS in link order); split_instances: emit two half-masks per link, to exercise the

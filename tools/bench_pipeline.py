@@ -6,6 +6,7 @@
 Random network weights (none exist offline): detections and therefore predictions are meaningless, the frame rate
 of the whole pipeline is what this measures.  min_confidence 0 keeps all 100 detections per frame (worst case)."""
 import argparse, os, sys, tempfile, time
+os.environ['ROPE_TIMING'] = '1'      # predict_dataset prints set-up and frame time apart
 import numpy as np
 import torch
 torch.cuda.init()        # torch's bundled HIP runtime has to come up before librope_hip.so brings in the system one
