@@ -121,6 +121,8 @@ struct rope_ctx {
     unsigned long long *d_toff = nullptr, *d_tused = nullptr;
     float4 *d_tgval = nullptr;
     uint64_t *d_ttotal = nullptr;
+    float *d_tc = nullptr;                  // rope_lookup_score: the cropped target, rows padded to whole groups (table_crop_words)
+    size_t tc_cap = 0;
     size_t trow_cap = 0;
     int table_C = 0, table_crop[4] = {0, 0, 0, 0};
     size_t table_groups = 0;                   // groups the stored table holds
@@ -365,7 +367,7 @@ extern "C" void rope_destroy(rope_ctx *c)
                     c->d_cand, c->d_err, c->d_best_err, c->d_mvp, c->d_bounds, c->d_mask_lo, c->d_mask_hi, c->d_layer_of, c->d_layer_rep, c->d_layers, c->d_layer_sums, c->d_parent_of, c->d_parent_rep, c->d_parents, c->d_table, c->d_tcount, c->d_toff, c->d_tused, c->d_tgoff, c->d_tgval, c->d_ttotal, c->d_zero_total, c->d_tsums, c->d_terr, c->d_qitems, c->d_tile_tris, c->d_tile_tris_lo, c->d_qctr, c->d_touched, c->d_gtile, c->d_aabb, c->d_sums, c->d_best_idx, c->d_key,
                     c->d_depth, c->d_ids, c->d_cover, c->d_ftq, c->d_ftl, c->d_ftotal, c->d_fempty, c->d_ft32, c->d_vstage, c->d_empty[0], c->d_empty[1], c->d_empty[2], c->d_empty[3],
                     c->d_total[0], c->d_total[1], c->d_total[2], c->d_total[3], c->d_fts32, c->d_fflags, c->d_tg_total[0], c->d_tg_total[1], c->d_tg_total[2],
-                    c->d_tg_total[3], c->d_tg_empty, c->d_frame_of, c->d_tg_t32c, c->d_tg_ltotal, c->d_tg_scores, c->d_tg_best, c->d_t32ts,
+                    c->d_tg_total[3], c->d_tg_empty, c->d_frame_of, c->d_tg_t32c, c->d_tg_ltotal, c->d_tg_scores, c->d_tg_best, c->d_t32ts, c->d_tc,
                     c->s_ftq, c->s_ft32, c->s_fts32, c->s_fflags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -510,7 +512,7 @@ extern "C" int rope_set_camera(rope_ctx *c, const double *PV, int W, int H, doub
         HIP_TRY(c, realloc_dev(&c->d_t32, n));
         HIP_TRY(c, realloc_dev(&c->d_t32ts, n));
         HIP_TRY(c, realloc_dev(&c->d_key, n));
-        HIP_TRY(c, realloc_dev(&c->d_depth, n + 4));         // + 4: the cropped target of rope_lookup_score is read up to three floats past its end
+        HIP_TRY(c, realloc_dev(&c->d_depth, n));
         HIP_TRY(c, realloc_dev(&c->d_ids, n));
         HIP_TRY(c, realloc_dev(&c->d_cover, n));
         for (int k = 0; k < 4; k++) {
@@ -1517,7 +1519,14 @@ extern "C" int rope_lookup_score(rope_ctx *c, double *scores_out, int32_t *best_
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
     const double n_pix = (double)(fp.r1 - fp.r0 + 1) * (double)(fp.c1 - fp.c0 + 1);
-    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_tcount, c->d_toff, c->d_tgoff, c->d_tgval, c->table_C, c->d_t32, c->d_depth /* scratch: H x W + 4 floats */,
+    const size_t words = table_crop_words(fp);
+    if (words > c->tc_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->tc_cap = 0;
+        HIP_TRY(c, realloc_dev(&c->d_tc, words));
+        c->tc_cap = words;
+    }
+    HIP_TRY(c, launch_table_score(c->stream, fp, c->d_tcount, c->d_toff, c->d_tgoff, c->d_tgval, c->table_C, c->d_t32, c->d_tc,
                                   c->d_ttotal, c->d_tsums));
     HIP_TRY(c, launch_finalize(c->stream, c->d_tsums, c->d_zero_total, c->table_C, ROPE_LOSS_LOOKUP, ROPE_MAX_LINKS, n_pix, c->lf, c->d_terr));
     if (scores_out) HIP_TRY(c, hipMemcpyAsync(scores_out, c->d_terr, (size_t)c->table_C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1837,12 +1846,11 @@ extern "C" int rope_lookup_score_targets(rope_ctx *c, int32_t *best_idx, double 
     HIP_TRY(c, hipSetDevice(c->device));
     FrameParams fp = c->fp;
     fp.r0 = c->table_crop[0]; fp.r1 = c->table_crop[1]; fp.c0 = c->table_crop[2]; fp.c1 = c->table_crop[3];
-    const size_t crop_px = (size_t)(fp.r1 - fp.r0 + 1) * (size_t)(fp.c1 - fp.c0 + 1), N = (size_t)c->n_targets;
-    if (N * crop_px > c->tg_t32c_cap) {           // + 4: a group at the crop's right edge reads up to three floats past the last frame's crop
+    const size_t crop_px = table_crop_words(fp), N = (size_t)c->n_targets;     // crop rows padded to whole groups of four samples
+    if (N * crop_px > c->tg_t32c_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->tg_t32c_cap = 0;
-        HIP_TRY(c, realloc_dev(&c->d_tg_t32c, N * crop_px + 4));
-        HIP_TRY(c, hipMemsetAsync(c->d_tg_t32c, 0, (N * crop_px + 4) * sizeof(float), c->stream));
+        HIP_TRY(c, realloc_dev(&c->d_tg_t32c, N * crop_px));
         c->tg_t32c_cap = N * crop_px;
     }
     if (N * c->table_C > c->tg_scores_cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->tg_scores_cap = 0; HIP_TRY(c, realloc_dev(&c->d_tg_scores, N * c->table_C)); c->tg_scores_cap = N * c->table_C; }

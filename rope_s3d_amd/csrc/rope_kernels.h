@@ -183,8 +183,15 @@ hipError_t launch_finalize(hipStream_t st, uint64_t *sums, const uint64_t *total
 hipError_t launch_table_count(hipStream_t st, int cw, int ch, const float *table, int C, uint32_t *counts, unsigned long long *offs,
                               unsigned long long *used);
 hipError_t launch_table_fill(hipStream_t st, int cw, int ch, const float *table, int C, const unsigned long long *offs, uint32_t *goff, float4 *gval);
+// floats of one frame's cropped target (t32c) as the table kernels lay it out: crop rows padded to whole
+// groups of four samples
+static inline size_t table_crop_words(const FrameParams &fp)
+{
+    return (size_t)(((fp.c1 - fp.c0 + 1) + 3) / 4) * 4 * (size_t)(fp.r1 - fp.r0 + 1);
+}
 // score every row of a stored lookup table against the float32 target plane
-// t32c: scratch of crop_h x crop_w + 4 floats (the cropped target, rebuilt by every call); total: ROPE_SUM_WORDS words of scratch
+// t32c: scratch of table_crop_words floats (the cropped target, rebuilt by every call);
+// total: ROPE_SUM_WORDS words of scratch
 hipError_t launch_table_score(hipStream_t st, const FrameParams &fp, const uint32_t *counts, const unsigned long long *offs, const uint32_t *goff,
                               const float4 *gval, int C, const float *t32, float *t32c, uint64_t *total, uint64_t *sums);
 // batches over several frames' targets (rope_eval_targets / rope_lookup_score_targets)
@@ -192,7 +199,7 @@ hipError_t launch_finalize_frames(hipStream_t st, uint64_t *sums, const uint64_t
                                   const LinkFlags *flags /* per frame, device */, int C, int loss, int n_render, double n_pix, double *err /* C */);
 // first argmin of n_sets sets of C doubles: best[2 k] error, best[2 k + 1] index
 hipError_t launch_argmin_sets(hipStream_t st, const double *err, int C, int n_sets, double *best);
-// the stored table against the float32 planes of n_frames frames: t32c n_frames x crop + 4 floats of scratch, totals n_frames x
+// the stored table against the float32 planes of n_frames frames: t32c n_frames x table_crop_words floats of scratch, totals n_frames x
 // SUM_WORDS of scratch, scores n_frames x C, best n_frames x 2 (score, row)
 hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, const uint32_t *counts, const unsigned long long *offs,
                                      const uint32_t *goff, const float4 *gval, int C, const float *t32, int n_frames, float *t32c, uint64_t *totals,

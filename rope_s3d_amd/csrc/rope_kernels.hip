@@ -154,8 +154,9 @@ __device__ static inline float linear_depth(uint32_t d24, float c_num, float c_s
     return c_num / den;
 }
 
-// floor(z * 2^32) for a finite z >= 0, by shifting the significand (same value as (uint64_t)((double)z * 2^32)).
-__device__ static inline uint64_t q32_of_f32(float z)
+// floor(z * 2^32) for a finite z >= 0 (same value as (uint64_t)((double)z * 2^32)).
+// Any size: by shifting the significand.
+__device__ static inline uint64_t q32_of_f32_wide(float z)
 {
     const uint32_t b = __float_as_uint(z);
     const int ex = (int)(b >> 23) & 0xFF;
@@ -163,6 +164,17 @@ __device__ static inline uint64_t q32_of_f32(float z)
     const uint64_t m = ex ? (uint64_t)((b & 0x7FFFFFu) | 0x800000u) : 0ull;
     const int sh = ex - 127 - 23 + 32;                        // z = m * 2^(ex-150)
     return (m << min(max(sh, 0), 63)) >> min(max(-sh, 0), 63);
+}
+
+// Below 2^32 (every depth and depth difference there is: the far plane is at 100 m) in five full-rate operations instead of a
+// dozen with 64-bit shifts: z = trunc(z) + fraction, both parts exact in float32; the integer part is the high word, and
+// fraction * 2^32 — a power-of-two scaling, exact, below 2^32 — truncated is the low word.
+__device__ static inline uint64_t q32_of_f32(float z)
+{
+    if (__builtin_expect(!(z < 4294967296.0f), 0)) return q32_of_f32_wide(z);
+    const float whole = truncf(z);
+    const uint32_t hi = (uint32_t)whole, lo = (uint32_t)((z - whole) * 4294967296.0f);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // floor(sqrt(x) * 2^32) for x given in Q32: sqrt(dq * 2^-32) * 2^32 = sqrt(dq) * 2^16; one correctly rounded
@@ -1432,26 +1444,33 @@ score_gtile_kernel(FrameParams fp, RasterArgs ra)
 // (table_count_kernel / table_fill_kernel), the sums of |T| over the whole crop are taken once per frame (crop_total_kernel), and
 // a row's sums are total + sum over its groups of (|T - D| - |T|) — integers, so exactly the sums over the whole crop.
 
-// One workgroup: the crop of the target plane as one contiguous array laid out like the crop (no index arithmetic on the
-// image per sample later), and the sums of |T| over it.
+// One workgroup: the crop of the target plane as one contiguous array — rows padded with zeros to a multiple of four samples, so
+// that a group of the table (columns 4k .. 4k+3 of a crop row) is one aligned float4 at offset 4 x (its number) — and the sums of |T|
+// over it.  (The same sums group by group, for a table row to subtract instead of working them out again per (row, frame), made the
+// scoring kernel half as slow again, 9.8 against 6.6 ms for 256 frames x 15 625 rows: it waits for its gathers, not for its arithmetic.)
 // grid = frames: frame f's plane starts f planes into t32, its crop f crops into t32c, its totals f x ROPE_SUM_WORDS into total
 __global__ void __launch_bounds__(1024)
 crop_total_kernel(FrameParams fp, const float *__restrict__ t32, float *__restrict__ t32c, uint64_t *__restrict__ total /* ROPE_SUM_WORDS */)
 {
     __shared__ uint64_t lds[4];
-    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1, n = cw * ch;
+    const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1, gw = (cw + 3) >> 2, n_groups = gw * ch;
     t32 += (size_t)blockIdx.x * fp.W * fp.H;
-    t32c += (size_t)blockIdx.x * n;
+    t32c += (size_t)blockIdx.x * n_groups * 4;
     total += (size_t)blockIdx.x * ROPE_SUM_WORDS;
     if (threadIdx.x < 4) lds[threadIdx.x] = 0;
     __syncthreads();
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int r = i / cw, c = i - r * cw;
-        const float t = t32[(size_t)(fp.r0 + r) * fp.W + fp.c0 + c];
-        t32c[i] = t;
-        acc_sq<false>(s, q32_of_f32(fabsf(t - 0.0f)));
+    for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        const int r = g / gw, c = 4 * (g - r * gw);
+        const float *src = t32 + (size_t)(fp.r0 + r) * fp.W + fp.c0 + c;
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t[j] = c + j < cw ? src[j] : 0.0f;
+            acc_sq<false>(s, q32_of_f32(fabsf(t[j] - 0.0f)));
+        }
+        reinterpret_cast<float4 *>(t32c)[g] = make_float4(t[0], t[1], t[2], t[3]);
     }
     const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
 #pragma unroll
@@ -1472,9 +1491,10 @@ crop_total_kernel(FrameParams fp, const float *__restrict__ t32, float *__restri
 // Build time.  A dense row (the cropped sqrt-depth image of one grid pose) is mostly zeros: the crop is the box of every pose of the
 // grid together, one pose covers a fraction of it, and the robot a fraction of its own bounding box.  A sample that holds nothing
 // contributes |T - 0| - |T| = 0 to the row's sums, exactly — so the stored table keeps only the GROUPS of four consecutive samples
-// of a crop row (columns 4k .. 4k+3) in which anything was drawn: per group the offset of its first sample inside the crop and
-// its four values (columns past the crop's edge read as 0).  table_count_kernel counts a row's groups and reserves their place,
-// table_fill_kernel writes them (in any order: the sums are integers).
+// of a crop row (columns 4k .. 4k+3) in which anything was drawn: per group four times its number — the offset of its first
+// sample in a crop whose rows are padded to whole groups (crop_total_kernel's layout) — and its four values (columns past the
+// crop's edge read as 0).  table_count_kernel counts a row's groups and reserves their place,
+// table_fill_kernel writes them (in the order of their place in the crop: neighbouring lanes then read neighbouring samples).
 __global__ void __launch_bounds__(256)
 table_count_kernel(int cw, int ch, const float *__restrict__ table, uint32_t *__restrict__ counts, unsigned long long *__restrict__ offs,
                    unsigned long long *__restrict__ used)
@@ -1503,34 +1523,44 @@ __global__ void __launch_bounds__(256)
 table_fill_kernel(int cw, int ch, const float *__restrict__ table, const unsigned long long *__restrict__ offs, uint32_t *__restrict__ goff,
                   float4 *__restrict__ gval)
 {
-    __shared__ int s_n;
-    const int gw = (cw + 3) >> 2, n_groups = gw * ch;
+    // The groups of a row are written IN ORDER of their place in the crop: the scoring kernels hand consecutive groups to
+    // consecutive lanes, and a run of groups inside the robot's outline is then a run of neighbouring 16-byte pieces of the target —
+    // eight lanes to a cache line instead of one line per lane.
+    __shared__ int s_wave[4];
+    const int gw = (cw + 3) >> 2, n_groups = gw * ch, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *row = table + (size_t)blockIdx.x * cw * ch;
     const unsigned long long base = offs[blockIdx.x];
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
-        const int r = g / gw, c = 4 * (g - r * gw);
-        float v[4];
+    int running = 0;
+    for (int g0 = 0; g0 < n_groups; g0 += 256) {
+        const int g = g0 + (int)threadIdx.x;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         bool any = false;
-        for (int j = 0; j < 4; j++) { v[j] = c + j < cw ? row[(size_t)r * cw + c + j] : 0.0f; any = any || v[j] != 0.0f; }
-        if (!any) continue;
-        const int pos = atomicAdd(&s_n, 1);
-        goff[base + pos] = (uint32_t)(r * cw + c);
-        gval[base + pos] = make_float4(v[0], v[1], v[2], v[3]);
+        if (g < n_groups) {
+            const int r = g / gw, c = 4 * (g - r * gw);
+            for (int j = 0; j < 4; j++) { v[j] = c + j < cw ? row[(size_t)r * cw + c + j] : 0.0f; any = any || v[j] != 0.0f; }
+        }
+        const unsigned long long b = __ballot(any);
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 4; w++) { before += w < wave ? s_wave[w] : 0; all += s_wave[w]; }
+        if (any) {
+            const int pos = running + before + __popcll(b & ((1ull << lane) - 1ull));
+            goff[base + pos] = (uint32_t)(4 * g);
+            gval[base + pos] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        running += all;
+        __syncthreads();
     }
 }
 
-// One group against one cropped target: s += sum of |T - D| minus sum of |T| over its four samples (words S1, AA, AB, BB), modulo
-// 2^64.  The target array is readable three floats past its end (a group at the crop's right edge holds zeros there, and what it
-// reads of the next row cancels).
-__device__ static inline void table_group_delta(uint32_t off, const float4 d, const float *__restrict__ t32c, uint64_t *s)
+// One group against one cropped target: s += sum of |T - D| minus sum of |T| over its four samples (words S1, AA, AB, BB), modulo 2^64.
+__device__ static inline void table_group_delta(const float4 t, const float4 d, uint64_t *s)
 {
-    const float t0 = t32c[off], t1 = t32c[off + 1], t2 = t32c[off + 2], t3 = t32c[off + 3];
-    acc_sq<false>(s, q32_of_f32(fabsf(t0 - d.x))); acc_sq<true>(s, q32_of_f32(fabsf(t0 - 0.0f)));
-    acc_sq<false>(s, q32_of_f32(fabsf(t1 - d.y))); acc_sq<true>(s, q32_of_f32(fabsf(t1 - 0.0f)));
-    acc_sq<false>(s, q32_of_f32(fabsf(t2 - d.z))); acc_sq<true>(s, q32_of_f32(fabsf(t2 - 0.0f)));
-    acc_sq<false>(s, q32_of_f32(fabsf(t3 - d.w))); acc_sq<true>(s, q32_of_f32(fabsf(t3 - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t.x - d.x))); acc_sq<true>(s, q32_of_f32(fabsf(t.x - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t.y - d.y))); acc_sq<true>(s, q32_of_f32(fabsf(t.y - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t.z - d.z))); acc_sq<true>(s, q32_of_f32(fabsf(t.z - 0.0f)));
+    acc_sq<false>(s, q32_of_f32(fabsf(t.w - d.w))); acc_sq<true>(s, q32_of_f32(fabsf(t.w - 0.0f)));
 }
 
 __global__ void __launch_bounds__(256)
@@ -1544,7 +1574,7 @@ table_score_kernel(const uint32_t *__restrict__ counts, const unsigned long long
     const unsigned long long base = offs[blockIdx.x];
     uint64_t s[ROPE_SUM_WORDS];
     s[SUM_S1] = s[SUM_AA] = s[SUM_AB] = s[SUM_BB] = 0;
-    for (int g = threadIdx.x; g < n; g += blockDim.x) table_group_delta(goff[base + g], gval[base + g], t32c, s);
+    for (int g = threadIdx.x; g < n; g += blockDim.x) table_group_delta(*reinterpret_cast<const float4 *>(t32c + goff[base + g]), gval[base + g], s);
     const int words[4] = {SUM_S1, SUM_AA, SUM_AB, SUM_BB};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1564,12 +1594,14 @@ table_score_kernel(const uint32_t *__restrict__ counts, const unsigned long long
 __device__ static inline double mean_std_parts(const uint64_t *s, double N, double &m1);
 
 // The same for the targets of many frames (rope_lookup_score_targets): grid = (table rows, frame chunks), and inside a workgroup
-// ONE WAVE per (row, frame) pair — a row's few hundred groups are a handful per lane, so a pair needs no barrier and no LDS: the
-// lanes' partial sums meet by lane exchange and lane 0 writes the finished lookup score (finalize_one's steps for ROPE_LOSS_LOOKUP
-// on the same sums: same bits) to scores[frame x rows + row].  The row's groups come from HBM once and from the cache for the
-// other frames.
+// ONE WAVE per (row, TABLE_FRAMES frames) — a row's few hundred groups are a handful per lane, so this needs no barrier and no LDS:
+// a lane reads a group of the row once and holds it against TABLE_FRAMES frames' samples at that place (their loads in flight
+// together), the lanes' partial sums meet by lane exchange and lane 0 writes the finished lookup scores (finalize_one's
+// steps for ROPE_LOSS_LOOKUP on the same sums: same bits) to scores[frame x rows + row].  The kernel lives on its arithmetic
+// (two Q32 conversions and six 64-bit multiply-adds per sample) and on the waves in flight: few frames per wave, see the launch.
+template <int TABLE_FRAMES>
 __global__ void __launch_bounds__(256)
-table_score_frames_kernel(int crop_px, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ offs,
+table_score_frames_kernel(int crop_px /* padded: 4 x groups */, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ offs,
                           const uint32_t *__restrict__ goff, const float4 *__restrict__ gval, const float *__restrict__ t32c /* frames x crop_px */,
                           const uint64_t *__restrict__ totals /* frames x ROPE_SUM_WORDS */, int n_frames, double n_pix,
                           double *__restrict__ scores)
@@ -1577,26 +1609,43 @@ table_score_frames_kernel(int crop_px, const uint32_t *__restrict__ counts, cons
     const int n = (int)counts[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long base = offs[blockIdx.x];
     const int per = (n_frames + (int)gridDim.y - 1) / (int)gridDim.y, f_lo = (int)blockIdx.y * per, f_hi = min(f_lo + per, n_frames);
-    for (int f = f_lo + wave; f < f_hi; f += 4) {
-        const float *__restrict__ t = t32c + (size_t)f * crop_px;
-        uint64_t s[ROPE_SUM_WORDS];
+    for (int f0 = f_lo + wave * TABLE_FRAMES; f0 < f_hi; f0 += 4 * TABLE_FRAMES) {
+        const int nf = min(TABLE_FRAMES, f_hi - f0);
+        uint64_t s[TABLE_FRAMES][SUM_BB + 1];
 #pragma unroll
-        for (int k = 0; k < ROPE_SUM_WORDS; k++) s[k] = 0;
-        for (int g = lane; g < n; g += 64) table_group_delta(goff[base + g], gval[base + g], t, s);
+        for (int j = 0; j < TABLE_FRAMES; j++)
 #pragma unroll
-        for (int k = SUM_S1; k <= SUM_BB; k++) {
-            uint64_t v = s[k];
+            for (int k = 0; k <= SUM_BB; k++) s[j][k] = 0;
+        const float *__restrict__ t0 = t32c + (size_t)f0 * crop_px;
+        for (int g = lane; g < n; g += 64) {
+            const uint32_t off = goff[base + g];
+            const float4 d = gval[base + g];
+            float4 t[TABLE_FRAMES];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            s[k] = v;
+            for (int j = 0; j < TABLE_FRAMES; j++)
+                t[j] = j < nf ? *reinterpret_cast<const float4 *>(t0 + (size_t)j * crop_px + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < TABLE_FRAMES; j++) table_group_delta(t[j], d, s[j]);
         }
-        if (lane == 0) {
-            const uint64_t *total = totals + (size_t)f * ROPE_SUM_WORDS;
 #pragma unroll
-            for (int k = SUM_S1; k <= SUM_BB; k++) s[k] += total[k];
-            double m1;
-            const double sd = mean_std_parts(s, n_pix, m1);
-            scores[(size_t)f * gridDim.x + blockIdx.x] = m1 * sd;
+        for (int j = 0; j < TABLE_FRAMES; j++) {
+            if (j >= nf) break;
+            uint64_t r[ROPE_SUM_WORDS];
+#pragma unroll
+            for (int k = SUM_S1; k <= SUM_BB; k++) {
+                uint64_t v = s[j][k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                r[k] = v;
+            }
+            if (lane == 0) {
+                const uint64_t *total = totals + (size_t)(f0 + j) * ROPE_SUM_WORDS;
+#pragma unroll
+                for (int k = SUM_S1; k <= SUM_BB; k++) r[k] += total[k];
+                double m1;
+                const double sd = mean_std_parts(r, n_pix, m1);
+                scores[(size_t)(f0 + j) * gridDim.x + blockIdx.x] = m1 * sd;
+            }
         }
     }
 }
@@ -1908,11 +1957,18 @@ hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, cons
 {
     const int cw = fp.c1 - fp.c0 + 1, ch = fp.r1 - fp.r0 + 1;
     hipLaunchKernelGGL(crop_total_kernel, dim3(n_frames), dim3(1024), 0, st, fp, t32, t32c, totals);
-    // a workgroup takes four frames at a time (a wave each): enough workgroups to fill the chip when the table is small; otherwise
-    // a row meets every frame in one workgroup
-    const int chunks = std::max(1, std::min((n_frames + 3) / 4, (4096 + C - 1) / C));
-    hipLaunchKernelGGL(table_score_frames_kernel, dim3(C, chunks), dim3(256), 0, st, cw * ch, counts, offs, goff, gval, t32c, totals, n_frames,
-                       (double)cw * (double)ch, scores);
+    // A workgroup takes 4 x F frames (F per wave), and the grid walks the table once per such chunk of frames (rows fastest): the
+    // chunk's cropped targets stay in L2 while every row gathers from them, and the table streams past once per chunk.
+    // Measured for 256 frames x 15 625 rows at 160x90 (tools/r03_tbl_run.sh): F = 8 7.2 ms (221 registers, two waves per SIMD),
+    // F = 4 5.1 ms, F = 2 4.8 ms; one frame per wave and every frame in one workgroup (round 3's first form) 6.6 ms.
+    static const int F = [] { const char *e = std::getenv("ROPE_TABLE_FRAMES"); const int v = e ? std::atoi(e) : 2; return v == 4 || v == 8 ? v : 2; }();
+    const int chunks = std::max(1, (n_frames + 4 * F - 1) / (4 * F));
+    const dim3 grid(C, chunks);
+    const int words = (int)table_crop_words(fp);
+    const double n_pix = (double)cw * (double)ch;
+    if (F == 2) hipLaunchKernelGGL(table_score_frames_kernel<2>, grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores);
+    else if (F == 4) hipLaunchKernelGGL(table_score_frames_kernel<4>, grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores);
+    else hipLaunchKernelGGL(table_score_frames_kernel<8>, grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores);
     hipLaunchKernelGGL(argmin_sets_kernel, dim3(n_frames), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, scores, C, best);
     return hipGetLastError();
 }
