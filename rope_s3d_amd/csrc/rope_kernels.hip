@@ -199,7 +199,8 @@ __device__ static inline void acc_sq(uint64_t *s, uint64_t dq)
 template <int LOSS, bool NEG = false>
 __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render, const uint64_t t /* tq[pix] */,
                                           const float ta /* t32[pix] */, const uint64_t *__restrict__ tl, size_t plane,
-                                          float c_num, float c_sum, float c_dif, uint64_t *s, uint64_t *pk = nullptr)
+                                          float c_num, float c_sum, float c_dif, uint64_t *s, uint64_t *pk = nullptr,
+                                          unsigned link_mask = 0xFFu /* ROPE_LOSS_FULL: the links whose terms are wanted (uniform) */)
 {
     const bool empty = (key == KEY_EMPTY);
     float z = empty ? 0.0f : linear_depth(key >> 8, c_num, c_sum, c_dif);
@@ -245,7 +246,7 @@ __device__ static inline void score_pixel(uint32_t key, size_t pix, int n_render
         const int id = empty ? 255 : (int)(key & 0xFF);
 #pragma unroll
         for (int l = 1; l < ROPE_MAX_LINKS; l++) {
-            if (l < n_render) {
+            if (l < n_render && ((link_mask >> l) & 1u)) {
                 const bool M = (mask >> l) & 1, R = (id == l);
                 const uint64_t a = M ? T : 0, b = R ? zq : 0;
                 const uint64_t dl = a > b ? a - b : b - a;
@@ -321,12 +322,26 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
                 for (int j = 0; j < 4; j++)
                     if (colg + j < fp.W) { if (USE_F) tf[j] = t32[pixg + j]; else tw[j] = tq[pixg + j]; }
             }
+            // ROPE_LOSS_FULL: a link's terms at a sample depend on the image only through "is this the link drawn here", so in
+            // sums(tile) - sums(base) every link that is drawn in neither cancels, sample by sample and exactly.  The links that
+            // are drawn somewhere in this wave's block (usually one or two of the five) are the only ones whose terms are worked
+            // out: a uniform branch per link, taken from a vote.
+            unsigned links = 0xFFu;
+            if (LOSS == ROPE_LOSS_FULL) {
+                unsigned mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (keys[j] != bas[j]) mine |= (keys[j] == KEY_EMPTY ? 0u : 1u << (keys[j] & 7u)) | (bas[j] == KEY_EMPTY ? 0u : 1u << (bas[j] & 7u));
+                links = 0;
+#pragma unroll
+                for (int l = 1; l < ROPE_MAX_LINKS; l++) links |= __ballot((mine >> l) & 1u) ? 1u << l : 0u;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (keys[j] == bas[j]) continue;
                 if (!pixel_active(row, colg + j, fp.W, fp.H, fp.r0, fp.r1, fp.c0, fp.c1)) continue;
-                score_pixel<LOSS, false>(keys[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk);
-                score_pixel<LOSS, true>(bas[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk);
+                score_pixel<LOSS, false>(keys[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk, links);
+                score_pixel<LOSS, true>(bas[j], pixg + j, n_render, tw[j], tf[j], tl, plane, fp.c_num, fp.c_sum, fp.c_dif, s, pk, links);
             }
         }
     } else {
@@ -363,6 +378,9 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
         const bool used = (LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) ? true : (k < SUM_LINK0);
         if (!used) continue;
         uint64_t v = s[k];
+        // a word nobody in the wave added to (the terms of a link that is drawn nowhere in the wave's block: most of the 20 words
+        // of the full loss) needs no exchange — the twelve steps of one cost more than a thread's share of the samples
+        if (__ballot(v != 0) == 0) continue;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)v);
