@@ -380,7 +380,7 @@ __device__ static inline void score_tile(const uint32_t *tile, const uint32_t *_
         uint64_t v = s[k];
         // a word nobody in the wave added to (the terms of a link that is drawn nowhere in the wave's block: most of the 20 words
         // of the full loss) needs no exchange — the twelve steps of one cost more than a thread's share of the samples
-        if (__ballot(v != 0) == 0) continue;
+        if ((LOSS == ROPE_LOSS_FULL || LOSS == ROPE_LOSS_CAMFULL) && __ballot(v != 0) == 0) continue;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)&lds_sums[k], (unsigned long long)v);
