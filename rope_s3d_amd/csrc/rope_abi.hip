@@ -320,28 +320,30 @@ extern "C" void rope_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-// `stream` / `block`: the context's own stream and pinned block by default; rope_stage_targets passes the upload stream and a block of its own
-static int copy_h2d_on(rope_ctx *c, hipStream_t stream, unsigned char **block, void *dst, const void *src, size_t bytes)
+// `stream` / `block` / `err`: the context's own stream, pinned block and message by default; rope_stage_targets, which may run beside
+// an evaluation on another thread, passes the upload stream and a block and a message of its own
+static int copy_h2d_on(hipStream_t stream, unsigned char **block, std::string &err, void *dst, const void *src, size_t bytes)
 {
     constexpr size_t CHUNK = 8u << 20;
-    if (bytes >= (64u << 10) && is_pinned_host(src)) {     // already page-locked: one copy at the link's rate, no staging; the caller synchronises
-        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-        return ROPE_OK;
-    }
-    if (!*block) HIP_TRY(c, hipHostMalloc((void **)block, 2 * CHUNK, hipHostMallocDefault));   // two halves, alternating
+    auto failed = [&](hipError_t e, const char *what) { if (e != hipSuccess) err = std::string(what) + ": " + hipGetErrorString(e); return e != hipSuccess; };
+    if (bytes >= (64u << 10) && is_pinned_host(src))       // already page-locked: one copy at the link's rate, no staging; the caller synchronises
+        return failed(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (host to device)") ? ROPE_E_HIP : ROPE_OK;
+    if (!*block && failed(hipHostMalloc((void **)block, 2 * CHUNK, hipHostMallocDefault), "hipHostMalloc (copy block)")) return ROPE_E_HIP;   // two halves, alternating
     int half = 0;
     for (size_t off = 0; off < bytes; off += CHUNK, half ^= 1) {
         const size_t n = std::min(CHUNK, bytes - off);
-        if (off >= 2 * CHUNK || off == 0) HIP_TRY(c, hipStreamSynchronize(stream));   // the half about to be overwritten is free again
+        // the half about to be overwritten is free again
+        if ((off >= 2 * CHUNK || off == 0) && failed(hipStreamSynchronize(stream), "hipStreamSynchronize (copy block)")) return ROPE_E_HIP;
         std::memcpy(*block + half * CHUNK, static_cast<const unsigned char *>(src) + off, n);
-        HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, *block + half * CHUNK, n, hipMemcpyHostToDevice, stream));
+        if (failed(hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, *block + half * CHUNK, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (host to device)"))
+            return ROPE_E_HIP;
     }
     return ROPE_OK;
 }
 
 static int copy_h2d_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
 {
-    return copy_h2d_on(c, c->stream, &c->h_copy, dst, src, bytes);
+    return copy_h2d_on(c->stream, &c->h_copy, c->err, dst, src, bytes);
 }
 
 static int copy_d2h_staged(rope_ctx *c, void *dst, const void *src, size_t bytes)
@@ -1721,6 +1723,7 @@ extern "C" int rope_stage_targets(rope_ctx *c, int n_frames, const uint64_t *tq,
     if (!c) return ROPE_E_ARG;
     // this call may run beside an evaluation on another thread: its failures are reported through the return code and a message of its own
     auto fail = [&](int code, const char *msg) { c->stage_err = msg; return code; };
+    c->stage_err.clear();
     if (!c->have_camera) return fail(ROPE_E_ARG, "rope_stage_targets: call rope_set_camera first (image size)");
     if (!tq || !link_flags || n_frames < 1 || n_frames > 65535) return fail(ROPE_E_ARG, "rope_stage_targets: need 1 <= n_frames <= 65535, tq and link_flags");
     if (hipSetDevice(c->device) != hipSuccess) return fail(ROPE_E_HIP, "rope_stage_targets: hipSetDevice failed");
@@ -1744,13 +1747,12 @@ extern "C" int rope_stage_targets(rope_ctx *c, int n_frames, const uint64_t *tq,
         if (realloc_dev(&c->s_fflags, (size_t)n_frames) == hipSuccess) c->s_fflags_cap = n_frames; else ok = false;
     }
     if (!ok) { (void)hipGetLastError(); return fail(ROPE_E_NOMEM, "rope_stage_targets: out of device memory"); }
-    std::string keep = c->err;                     // copy_h2d_on reports into c->err: move its message where this call's belong
     // the few bytes of flags first: a small (or pageable) source goes through the pinned block, which waits for the stream
-    int rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_fflags, link_flags, 8 * (size_t)n_frames);
-    if (!rc) rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_ftq, tq, n * sizeof(uint64_t));
-    if (!rc && t32) rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_ft32, t32, n * sizeof(float));
-    if (!rc && t32_tsweep) rc = copy_h2d_on(c, c->copy_stream, &c->h_copy2, c->s_fts32, t32_tsweep, n * sizeof(float));
-    if (rc) { c->stage_err = c->err; c->err = keep; return rc; }
+    int rc = copy_h2d_on(c->copy_stream, &c->h_copy2, c->stage_err, c->s_fflags, link_flags, 8 * (size_t)n_frames);
+    if (!rc) rc = copy_h2d_on(c->copy_stream, &c->h_copy2, c->stage_err, c->s_ftq, tq, n * sizeof(uint64_t));
+    if (!rc && t32) rc = copy_h2d_on(c->copy_stream, &c->h_copy2, c->stage_err, c->s_ft32, t32, n * sizeof(float));
+    if (!rc && t32_tsweep) rc = copy_h2d_on(c->copy_stream, &c->h_copy2, c->stage_err, c->s_fts32, t32_tsweep, n * sizeof(float));
+    if (rc) return rc;
     c->staged_t32 = (t32 != nullptr);
     c->staged_ts = (t32_tsweep != nullptr);
     c->staged_W = W; c->staged_H = H;

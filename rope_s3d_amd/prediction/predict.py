@@ -491,10 +491,10 @@ class Predictor:
                 del filled[k]
                 if k + 2 < len(groups):
                     filled[k + 2] = submit(k + 2)
+                if camera_poses is not None and np.any(np.asarray(camera_poses[lo]) != self.camera_pose):
+                    self.changeCameraPose(camera_poses[lo])     # before the uploader touches the context again
                 if k + 1 < len(groups):
                     staging = uploader.submit(stage, filled[k + 1])
-                if camera_poses is not None and np.any(np.asarray(camera_poses[lo]) != self.camera_pose):
-                    self.changeCameraPose(camera_poses[lo])
                 out[lo:hi] = self._run_resident(hi - lo)
         return out
 

@@ -225,6 +225,26 @@ def test_predict_batch_equals_frame_by_frame_and_the_reference(do_angles, table)
             assert np.array_equal(a_ref, a_got), f"frame {i} stage {k_got}"
 
 
+def test_run_many_with_camera_poses_that_change_between_groups():
+    """run_many groups consecutive frames under one camera pose; a change of pose falls between two groups — after the commit of
+    one group's staged targets and before the upload of the next — and every frame gets the angles of run() with its own pose."""
+    from rope_s3d_amd import SyntheticPredictor
+    pose_a = np.array(DEFAULT_CAMERA_POSE, float)
+    pose_b = pose_a + np.array([0.05, -0.1, 0.03, 0.0, 0.02, -0.04])
+    sp = SyntheticPredictor(pose_a, '640_480_color', 4, 'SL', noise=False, seed=8, lookup_divisions=4)
+    p = sp.predictor
+    lim = helpers.robot().joint_limits
+    colors, depths, poses = [], [], []
+    for k, (pose, n) in enumerate([(pose_a, 5), (pose_b, 6), (pose_a, 3)]):
+        sp.renderer.setCameraPose(pose)
+        for _, c, d in _frames(sp.renderer, lim, n, 500 + k):
+            colors.append(c); depths.append(d); poses.append(pose.copy())
+    many = p.run_many(colors, depths, camera_poses=np.array(poses), batch=4)
+    for i in range(len(colors)):
+        one = p.run(colors[i], depths[i], poses[i])
+        assert np.array_equal(_bits(one), _bits(many[i])), f"frame {i}"
+
+
 def test_predict_batch_segmentation_path_and_tensor_sweep():
     """The segmentation path's targets (instance merge, dilate 8 / erode 7 body mask) through the batch, and a stage list with
     TensorSweep stages natively (ROPE_STAGE_TSWEEP): both equal the Python stage loop frame by frame."""
