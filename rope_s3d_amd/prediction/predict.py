@@ -8,6 +8,7 @@ changes is how a candidate is evaluated: every `render_at_pos` + `_error` pair o
 reference (predict.py:159-161,475-509) becomes one row of a batch handed to the HIP
 engine, which does FK, rasterisation and the error reduction on the device.
 """
+import os
 import warnings
 from dataclasses import dataclass
 from typing import Callable, Optional
@@ -97,6 +98,7 @@ class Predictor:
     BATCH = None       # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
                        # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..512 (512 up to
                        # 640x480, 194 at 1280x720); 1: frame after frame (rope_predict).  Same angles either way.
+    PREPARE_WORKERS = int(os.environ.get('ROPE_PREPARE_WORKERS', '8'))   # run_many: most threads that prepare the frames of the next batches
     BATCH_BYTES = 2 << 30   # two page-locked sets of this size on the host and two on the device (288 GB of HBM: a batch is small
                             # change).  640x480: 2 760 frames/s at 256 frames per batch, 3 280 at 512, the same at 1 024
 
@@ -463,7 +465,7 @@ class Predictor:
 
         # a segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order,
         # unless it says it keeps no state (`stateless`)
-        workers = max(1, min(8, cpu_budget() - 1)) if (self.synthetic or getattr(self.seg, 'stateless', False)) else 1
+        workers = max(1, min(self.PREPARE_WORKERS, cpu_budget() - 1)) if (self.synthetic or getattr(self.seg, 'stateless', False)) else 1
         with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as uploader:
             def submit(k):
                 lo_, hi_ = groups[k]
