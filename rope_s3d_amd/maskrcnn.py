@@ -18,6 +18,7 @@ The dense work is the only part of the prediction path where MFMA is the right t
 it (FK, raster, loss) is the hand-written HIP engine.
 """
 import math
+import os
 from typing import List
 
 import numpy as np
@@ -749,6 +750,11 @@ class MaskRCNNSegmenter:
             from .utils import limit_host_threads
             limit_host_threads()                                           # see there: idle pool threads spinning freeze the process under a CPU quota
             self.net = self.net.to(torch.bfloat16)
+            if os.environ.get('ROPE_SEG_FIND') == '1':
+                # MIOpen's find step (timed trials per convolution shape) instead of its immediate-mode pick: the batch of eight
+                # 13.4 instead of 15.7 ms (10.5 / 11.5 pipelined) for half a minute more of start-up on a machine without a
+                # find database of these shapes (profiles/r03_seg_trace.txt) — for long-running services, not for a 1 000-frame set
+                torch.backends.cudnn.benchmark = True
             for part in (self.net.fpn, self.net.rpn):                      # see detect_batch for the layouts
                 part.to(memory_format=torch.channels_last)
 
