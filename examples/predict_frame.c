@@ -21,6 +21,8 @@
  *   Predictor.run (predict.py:127-375)
  *     _downsample + _loadSynthetic + _load_target (predict.py:378-381,445-469,397-413)          rope_prepare_synthetic, rope_set_target
  *     the 'SLU' stage list (stages.py:152-168)                                                  rope_predict
+ *   the frame loop of predict_dataset.py:43-44 (optional second argument)          rope_host_alloc, rope_stage_targets / rope_commit_targets,
+ *                                                                                  rope_predict_batch
  */
 #include <math.h>
 #include <stdint.h>
@@ -73,7 +75,7 @@ static double as_printed(double x)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s <bundle directory>\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <bundle directory> [frames per lockstep batch]\n", argv[0]); return 2; }
     const char *dir = argv[1];
     size_t n_vo, n_color, n_depth;
     float *verts = load(dir, "verts.f32", 4, NULL);
@@ -165,6 +167,48 @@ int main(int argc, char **argv)
     for (int j = 0; j < 6; j++) printf("%.17g%c", angles[j], j == 5 ? '\n' : ' ');
     fprintf(stderr, "crop %d %d %d %d, %lld lookup poses, %lld candidate poses rendered and scored\n", crop[0], crop[1], crop[2], crop[3],
             (long long)n_grid, (long long)evals);
+
+    /* Optional second argument B: the frame loop of predict_dataset.py:43-44 as lockstep batches (rope_predict_batch) — two groups of
+     * B copies of the frame, each prepared into page-locked planes (rope_host_alloc), the second group's planes going up on the
+     * library's second stream (rope_stage_targets) while the first group is predicted.  Every copy must come out as the frame did. */
+    const int B = argc > 2 ? atoi(argv[2]) : 0;
+    if (B > 0) {
+        const size_t plane = (size_t)W * H;
+        uint64_t *btq[2];
+        float *bt32[2];
+        uint8_t *bfl[2];
+        for (int k = 0; k < 2; k++) {
+            btq[k] = rope_host_alloc(B * plane * sizeof(uint64_t));
+            bt32[k] = rope_host_alloc(B * plane * sizeof(float));
+            bfl[k] = malloc((size_t)B * 8);
+            if (!btq[k] || !bt32[k] || !bfl[k]) { fprintf(stderr, "no page-locked memory\n"); return 1; }
+        }
+        double *out = malloc((size_t)2 * B * 6 * sizeof(double));
+        if (!out) return 1;
+        a.speculate = B >= 16 ? 1 : 3;                    /* hundreds of rows per step anyway: the reference's own two renders at a time */
+        for (int g = 0; g < 2; g++) {
+            if (g == 0) {
+                for (int i = 0; i < B; i++)
+                    if (rope_prepare_synthetic(color, (int64_t)3 * W0, depth, 1, (int64_t)4 * W0, H0, W0, ds, link_blue, 6, 6, btq[0] + i * plane,
+                                               bt32[0] + i * plane, NULL, bfl[0] + 8 * i)) return 1;
+                CHECK(rope_stage_targets(ctx, B, btq[0], bt32[0], NULL, bfl[0]));
+            }
+            CHECK(rope_commit_targets(ctx));
+            if (g == 0) {                                 /* group 1 on its way up while group 0 is predicted */
+                for (int i = 0; i < B; i++)
+                    if (rope_prepare_synthetic(color, (int64_t)3 * W0, depth, 1, (int64_t)4 * W0, H0, W0, ds, link_blue, 6, 6, btq[1] + i * plane,
+                                               bt32[1] + i * plane, NULL, bfl[1] + 8 * i)) return 1;
+                CHECK(rope_stage_targets(ctx, B, btq[1], bt32[1], NULL, bfl[1]));
+            }
+            CHECK(rope_predict_batch(ctx, &a, B, out + (size_t)g * B * 6, NULL, NULL));
+        }
+        int same = 1;
+        for (int i = 0; i < 2 * B; i++) same = same && memcmp(out + 6 * i, angles, sizeof angles) == 0;
+        fprintf(stderr, "%d frames in two lockstep batches: %s\n", 2 * B, same ? "every one equal to the single frame" : "MISMATCH");
+        for (int k = 0; k < 2; k++) { rope_host_free(btq[k]); rope_host_free(bt32[k]); free(bfl[k]); }
+        free(out);
+        if (!same) return 3;
+    }
     rope_destroy(ctx);
     return 0;
 }

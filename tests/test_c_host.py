@@ -67,3 +67,10 @@ def test_c_host_predicts_the_same_angles_as_the_python_host(exe, tmp_path):
         assert np.array_equal(got, want), (got, want)
         c = p.lookup_crop
         assert f'crop {c[0]} {c[1]} {c[2]} {c[3]}, {len(p.lookup_angles)} lookup poses' in r.stderr
+        if seed == 0:
+            # the same frame 2 x 20 times through the lockstep path from C: page-locked planes, the second group staged while the
+            # first is predicted (rope_stage_targets / rope_commit_targets / rope_predict_batch)
+            r = subprocess.run([exe, bundle, '20'], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            assert '40 frames in two lockstep batches: every one equal to the single frame' in r.stderr
+            assert np.array_equal(np.array([float(x) for x in r.stdout.split()]), want)
