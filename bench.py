@@ -125,10 +125,10 @@ def cpu_baseline(robot, PV, W, H, znear, zfar, cand, tq, n_sample, gpu_err=None,
                       f"{dt:.2f} s wall; single thread: first {len(one)} candidates, {dt1:.2f} s"}
 
 
-def end_to_end(device, n_frames=2048):
+def end_to_end(device, n_frames=4096):
     """The whole prediction path at the metric's resolution on one engine context, after the timed region: n_frames synthetic
     640x480 RGB-D frames (already in host memory, as a camera or a dataset reader hands them over) through Predictor.run_many: lockstep
-    batches of 512, the next batch prepared on worker threads and uploaded on the engine's second stream while one is on the GPU —
+    batches of the default size (582 frames at this resolution), the next batch prepared on worker threads and uploaded on the engine's second stream while one is on the GPU —
     host preparation, upload, the Lookup stage (9^3 grid, the reference's size rule) and every stage of the 'SLU' list, the frames
     walking the stage list in lockstep batches (rope_predict_batch).  Poses = candidate poses rendered AND scored, lookup rows
     included.  Not `value`: an extra figure beside it."""

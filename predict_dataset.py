@@ -143,6 +143,6 @@ if __name__ == "__main__":
                         help="Predictors (engine contexts + threads) per GPU when the link masks come from the colour render; default 1: "
                              "one Predictor walking -batch frames in lockstep.")
     parser.add_argument('-batch', type=int, default=None,
-                        help="Frames that walk the stage list in lockstep (one device batch per step over all of them); default: by frame size, 16..512; 1: frame after frame.")
+                        help="Frames that walk the stage list in lockstep (one device batch per step over all of them); default: by frame size, 16..1024; 1: frame after frame.")
     parser.add_argument('-weights', type=str, default=None, help="weights for -segmenter maskrcnn: the reference's trained Keras .h5 or a torch state_dict (random weights otherwise).")
     run(parser.parse_args())

@@ -87,6 +87,25 @@ def segment_targets(seg: dict, target_depth: np.ndarray, lookup_links) -> np.nda
     return lookup_depth
 
 
+class _BatchTraces:
+    """Per-stage traces of a lockstep batch, frame by frame, as run() keeps them for one frame: entry f is
+    [(stage name, angles after the stage), ...].  Built when asked for — a batch of 512 frames is 4 600 small arrays."""
+
+    def __init__(self, trace: np.ndarray, names):
+        self._trace, self._names = trace, list(names)
+
+    def __len__(self):
+        return len(self._trace)
+
+    def __getitem__(self, f):
+        if isinstance(f, slice):
+            return [self[i] for i in range(*f.indices(len(self)))]
+        return [(name, self._trace[f, i].copy()) for i, name in enumerate(self._names)]
+
+    def __iter__(self):
+        return (self[f] for f in range(len(self)))
+
+
 class Predictor:
 
     SPECULATE = 3      # joints of a Descent iteration evaluated as one batch (1 = the reference's two renders at a time)
@@ -96,11 +115,12 @@ class Predictor:
     NATIVE = True      # run the stage loop in librope_hip.so (rope_predict); False: the Python loop below, same decisions
     NATIVE_PREPARE = True   # synthetic path: prepare() as one pass in the library (rope_prepare_synthetic); False: the numpy steps, same arrays
     BATCH = None       # run_many: frames that walk the stage list in lockstep, every step one device batch over all of them
-                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..512 (512 up to
-                       # 640x480, 194 at 1280x720); 1: frame after frame (rope_predict).  Same angles either way.
+                       # (rope_predict_batch).  None: as many as fit BATCH_BYTES of target planes, 16..1024 (1024 at 160x90,
+                       # 582 at 640x480, 194 at 1280x720); 1: frame after frame (rope_predict).  Same angles either way.
     PREPARE_WORKERS = int(os.environ.get('ROPE_PREPARE_WORKERS', '8'))   # run_many: most threads that prepare the frames of the next batches
     BATCH_BYTES = 2 << 30   # two page-locked sets of this size on the host and two on the device (288 GB of HBM: a batch is small
-                            # change).  640x480: 2 760 frames/s at 256 frames per batch, 3 280 at 512, the same at 1 024
+                            # change).  The more frames per batch, the shorter its tail of stragglers weighs: at the defaults
+                            # the stage machine alone does 8 540 frames/s with 512, 9 320 with 1 024, 10 340 with 2 048
 
     def __init__(self,
                  camera_pose: np.ndarray = DEFAULT_CAMERA_POSE,
@@ -425,7 +445,7 @@ class Predictor:
         angles, trace, n_eval = self.engine.predict_batch(self._native_stages(), self.u_reader.joint_limits, self.camera_pose, self.min_ang_inc,
                                                           self.lookup_angles, self.lookup_crop, self._lookup_table, speculate)
         self.evaluations += n_eval
-        self.traces = [[(type(stage).__name__, trace[f, i].copy()) for i, stage in enumerate(self.stages)] for f in range(n)]
+        self.traces = _BatchTraces(trace, [type(stage).__name__ for stage in self.stages])
         self.trace = self.traces[-1]
         return angles
 
@@ -463,6 +483,10 @@ class Predictor:
             if ts is not None:
                 ts[k] = prep.tgt_depth
 
+        def fill_run(planes, j0, j1, lo_):
+            for j in range(j0, j1):
+                fill(planes, j, lo_ + j)
+
         # a segmenter (a network on the GPU, or one that keeps per-chunk state) sees the frames one at a time and in order,
         # unless it says it keeps no state (`stateless`)
         workers = max(1, min(self.PREPARE_WORKERS, cpu_budget() - 1)) if (self.synthetic or getattr(self.seg, 'stateless', False)) else 1
@@ -473,7 +497,9 @@ class Predictor:
                 # two sets of planes in page-locked memory, taken in turn
                 tq, t32, fl, ts = self._plane_set(k & 1, min(batch, n), H, W, want_ts)
                 planes = (tq[:b], t32[:b], fl[:b], None if ts is None else ts[:b])
-                return planes, [pool.submit(fill, planes, j, lo_ + j) for j in range(b)]
+                # a few jobs per worker, each a run of consecutive frames (a job per frame costs the submitting thread 20 us each)
+                step = max(1, -(-b // (4 * workers)))
+                return planes, [pool.submit(fill_run, planes, j0, min(j0 + step, b), lo_) for j0 in range(0, b, step)]
 
             def stage(filled):
                 planes, jobs = filled
@@ -505,7 +531,7 @@ class Predictor:
         pixel and frame: uint64 + float32)."""
         if self.BATCH is not None:
             return int(self.BATCH)
-        return int(min(512, max(16, self.BATCH_BYTES // (12 * self.intrinsics.width * self.intrinsics.height))))
+        return int(min(1024, max(16, self.BATCH_BYTES // (12 * self.intrinsics.width * self.intrinsics.height))))
 
     def run_many(self, target_colors, target_depths, camera_poses=None, prefetch: bool = True, batch: int = None) -> np.ndarray:
         """run() over a sequence of frames -> (N, 6).  By default BATCH frames at a time walk the stage list in lockstep

@@ -7,8 +7,8 @@ OUT=$ROOT/gpurun_out/r03
 mkdir -p $OUT
 cd $ROOT
 if [ "$1" == "frames" ]; then      # second call (the two together exceed one gpurun call): the frame pipeline's tables
-    timeout -k 10 500 bash tools/r03_frames.sh > /dev/null 2>&1
-    timeout -k 10 500 bash tools/r03_prof_batch.sh > /dev/null 2>&1
+    timeout -k 10 650 bash tools/r03_frames.sh > /dev/null 2>&1
+    timeout -k 10 450 bash tools/r03_prof_batch.sh > /dev/null 2>&1
     cat $OUT/frames_batch.txt $OUT/prof_batch.txt
     exit 0
 fi
