@@ -13,7 +13,7 @@ from typing import Callable, List, Optional
 
 import numpy as np
 
-from ..constants import DEFAULT_CAMERA_POSE, ZFAR, ZNEAR
+from ..constants import DEFAULT_CAMERA_POSE, DEFAULT_RENDER_COLORS, ZFAR, ZNEAR
 from ..engine import LOSS_CAMFULL, LOSS_TSWEEP, pack_target
 from ..imgproc import resize_linear
 from ..projection import view_matrix
@@ -123,8 +123,6 @@ class _CameraStageMachine:
     zp_div_from_stage = True      # CameraPredictor's zp_sweep reads a stale `div` instead (see run_stages)
 
     def __init__(self, base_pose, ds_factor, preview, save_to, min_angle_inc, history_length, base_intrinsics, device):
-        if preview:
-            raise NotImplementedError("preview needs an OpenCV window (ModellessProjectionViz / ProjectionViz): out of scope")
         self.base_pose = np.array(base_pose, dtype=float)
         self.ds_factor, self.preview = ds_factor, preview
         self.min_ang_inc = np.asarray(min_angle_inc, dtype=float)
@@ -139,6 +137,32 @@ class _CameraStageMachine:
         self._P = self.renderer.intrinsics.gl_projection(ZNEAR, ZFAR)
         self.evaluations = 0          # (pose, frame) renders, for throughput accounting
         self.stages = None
+        if preview:                   # headless, as Predictor's: frames go to .viz.frame and, with save_to, an uncompressed AVI
+            from . import viz
+            self.viz = getattr(viz, self._viz_class)(save_to)
+
+    _viz_class = 'ModellessProjectionViz'
+
+    def _preview_targets(self, og_image, target_depth, links_image=None):
+        """What the reference loads into its window before the stages start (:140-142, :678-691): the first frame."""
+        if self.preview:
+            self.viz.loadTargetColor(np.asarray(og_image).astype(np.uint8))
+            self.viz.loadTargetDepth(target_depth)
+            if links_image is not None:
+                self.viz.loadSegmentedLinks(links_image)
+
+    def _preview_poses(self, poses: np.ndarray):
+        """preview_if_applicable (:160-167): one window frame per trial pose, showing the FIRST frame's render under it.  The
+        trial poses of a step are scored as one batch here; their preview frames follow in the same order."""
+        if not self.preview:
+            return
+        for pose in np.atleast_2d(poses):
+            self.renderer.setCameraPose(pose)
+            self.renderer.setJointAngles(self.robot_poses[0])
+            color, depth = self.renderer.render()
+            self.viz.loadRenderedColor(color)
+            self.viz.loadRenderedDepth(depth)
+            self.viz.show()
 
     # -- evaluation -------------------------------------------------------------------------------
     def _views(self, poses: np.ndarray) -> np.ndarray:
@@ -150,6 +174,7 @@ class _CameraStageMachine:
         step = max(1, 65535 // self.number_of_poses)
         out = [self.engine.eval_views(PV[k:k + step], 6, loss) for k in range(0, len(PV), step)]
         self.evaluations += len(PV) * self.number_of_poses
+        self._preview_poses(poses)
         return out[0] if len(out) == 1 else np.concatenate(out)
 
     def _errors(self, poses: np.ndarray) -> np.ndarray:          # `_error` of one pose's renders, per pose
@@ -353,6 +378,7 @@ class ModellessCameraPredictor(_CameraStageMachine):
 
     def run(self, og_images, target_depths, robot_poses, starting_camera_pose=None) -> np.ndarray:
         og_images, target_depths, pose = self._start(og_images, target_depths, robot_poses, starting_camera_pose)
+        self._preview_targets(og_images[0], target_depths[0])
         self._tgt_depths = self._batch_downsample(target_depths, self.ds_factor)
         self._n_pix = float(self._tgt_depths.shape[1] * self._tgt_depths.shape[2])
         self._frame_planes = (np.stack([pack_target(d) for d in self._tgt_depths]), self._tgt_depths.astype(np.float32))
@@ -381,6 +407,7 @@ class CameraPredictor(_CameraStageMachine):
     """Camera pose from segmented frames: per-link masks and depths plus the whole depth map (:576-975)."""
 
     zp_div_from_stage = False
+    _viz_class = 'ProjectionViz'
 
     def __init__(self, base_pose=DEFAULT_CAMERA_POSE, ds_factor: int = 8, preview: bool = False, save_to: str = None,
                  min_angle_inc=np.array([0.001, 0.001, 0.001, 0.002, 0.002, 0.002]), history_length=5,
@@ -434,9 +461,16 @@ class CameraPredictor(_CameraStageMachine):
 
     def run(self, og_images, target_depths, robot_poses, starting_camera_pose=None) -> np.ndarray:
         og_images, target_depths, pose = self._start(og_images, target_depths, robot_poses, starting_camera_pose)
+        full_color, full_depth = og_images[0], target_depths[0]
         target_depths = self._batch_downsample(target_depths, self.ds_factor)
         og_images = self._batch_downsample(og_images, self.ds_factor)
         segmentation_data = [self._reorganize_by_link(self.seg(og_images[idx].astype(np.uint8))) for idx in range(len(og_images))]
+        if self.preview:              # the window's "detected links": frame 0 with its links tinted (pixellib's annotated frame, :687-691)
+            tinted = og_images[0].astype(np.float64)
+            for name, d in segmentation_data[0].items():
+                if name in self.link_names:
+                    tinted[d['mask']] = tinted[d['mask']] * .5 + np.array(DEFAULT_RENDER_COLORS[self.link_names.index(name)], np.float64) * .5
+            self._preview_targets(full_color, full_depth, np.rint(tinted).astype(np.uint8))
         if self.stages is None:
             self._setStages()
         self._load_targets(segmentation_data, target_depths)

@@ -169,3 +169,14 @@ class ProjectionViz:
             self.close()
         except Exception:
             pass
+
+
+class ModellessProjectionViz(ProjectionViz):
+    """The modelless camera predictor's preview (camera_pose_prediction.py:502-575): the same four quadrants without the
+    detected links (that quadrant stays black)."""
+
+    def _genInput(self):
+        hh, hw = self.res[0] // 2, self.res[1] // 2
+        self.frame[:hh, :hw] = self._orig()
+        self.input_side_up_to_date = True
+

@@ -127,6 +127,34 @@ def test_modelless_predictor_trace_matches_sequential_reference(big_renderer, fs
     assert p.error_at(got) <= p.error_at(start)
 
 
+def test_camera_predictor_previews_are_headless_and_change_nothing(big_renderer, tmp_path):
+    """preview=True (ModellessProjectionViz / ProjectionViz, camera_pose_prediction.py:502-575,978-1056): one composed frame per
+    trial pose — the first frame's render under it — kept in .viz.frame and written to the video; the estimate is the same."""
+    from rope_s3d_amd import CameraPredictor, ModellessCameraPredictor
+    from rope_s3d_amd.prediction import camera_pose_prediction as cpp
+    from rope_s3d_amd.segmentation import ColorSegmenter
+    rb = helpers.robot()
+    qs, colors, depths = _frames(big_renderer, rb, 2, 77)
+    start = np.array(DEFAULT_CAMERA_POSE, float)
+    stages = [('smartsweep', 4, .1, cpp._XYZ), ('tensorsweep', 5, .1, cpp._RPY), ('descent', 3, 0.5, .001, [True] * 6, [0.01] * 6)]
+    seg = ColorSegmenter(['BG'] + rb.link_names[:6])
+    for cls, kwargs in ((ModellessCameraPredictor, {}), (CameraPredictor, {'segmenter': seg})):
+        plain = cls(start, 4, base_intrinsics='640_480_color', **kwargs)
+        plain.stages = list(stages)
+        want = plain.run(colors, depths.copy(), qs)
+        video = tmp_path / f'{cls.__name__}.avi'
+        shown = cls(start, 4, preview=True, save_to=str(video), base_intrinsics='640_480_color', **kwargs)
+        shown.stages = list(stages)
+        got = shown.run(colors, depths.copy(), qs)
+        assert np.array_equal(got, want)
+        assert shown.viz.shown == shown.evaluations // len(qs) > 10
+        frame = shown.viz.frame
+        assert frame.shape == (720, 1280, 3) and frame[:360, 640:].any() and frame[:360, :640].any()
+        assert frame[365:, :630].any() == (cls is CameraPredictor)              # the detected-links quadrant, inside the dividing lines
+        shown.viz.close()
+        assert video.stat().st_size > shown.viz.shown * 720 * 1280 * 3
+
+
 @pytest.mark.parametrize('fseed', [34 + 7 * k for k in range(int(__import__('os').environ.get('ROPE_CAM_TRACE_SEEDS', '1')))])
 def test_segmented_predictor_trace_matches_sequential_reference(big_renderer, fseed):
     from rope_s3d_amd import CameraPredictor
