@@ -1612,51 +1612,56 @@ table_score_kernel(const uint32_t *__restrict__ counts, const unsigned long long
 __device__ static inline double mean_std_parts(const uint64_t *s, double N, double &m1);
 
 // The same for the targets of many frames (rope_lookup_score_targets): grid = (table rows, frame chunks), and inside a workgroup
-// ONE WAVE per (row, TABLE_FRAMES frames) — a row's few hundred groups are a handful per lane, so this needs no barrier and no LDS:
-// a lane reads a group of the row once and holds it against TABLE_FRAMES frames' samples at that place (their loads in flight
-// together), the lanes' partial sums meet by lane exchange and lane 0 writes the finished lookup scores (finalize_one's
-// steps for ROPE_LOSS_LOOKUP on the same sums: same bits) to scores[frame x rows + row].  The kernel lives on its arithmetic
+// one group of LANES lanes per (row, TABLE_FRAMES frames) — a row's few hundred groups are a handful per lane, so this needs no
+// barrier and no LDS: a lane reads a group of the row once and holds it against TABLE_FRAMES frames' samples at that place (their
+// loads in flight together), the lanes' partial sums meet by lane exchange and the group's first lane writes the finished lookup
+// scores (finalize_one's steps for ROPE_LOSS_LOOKUP on the same sums: same bits) to scores[frame x rows + row].  The kernel lives on its arithmetic
 // (two Q32 conversions and six 64-bit multiply-adds per sample) and on the waves in flight: few frames per wave, see the launch.
-template <int TABLE_FRAMES>
+template <int TABLE_FRAMES, int LANES /* of a wave that share one frame: 64, or 16 (four frames side by side in a wave) */>
 __global__ void __launch_bounds__(256)
 table_score_frames_kernel(int crop_px /* padded: 4 x groups */, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ offs,
                           const uint32_t *__restrict__ goff, const float4 *__restrict__ gval, const float *__restrict__ t32c /* frames x crop_px */,
                           const uint64_t *__restrict__ totals /* frames x ROPE_SUM_WORDS */, int n_frames, double n_pix,
                           double *__restrict__ scores)
 {
-    const int n = (int)counts[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // With LANES = 16 a wave holds four frame groups side by side: a row's few hundred groups are then twenty per lane instead of
+    // five with the last step a third empty, the lane exchange is four steps instead of six and serves four times the frames, and
+    // the float64 epilogue of four frames runs in four lanes at once.
+    constexpr int PARTS = 64 / LANES, PER_WAVE = PARTS * TABLE_FRAMES;
+    const int n = (int)counts[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane / LANES, sub = lane % LANES;
     const unsigned long long base = offs[blockIdx.x];
     const int per = (n_frames + (int)gridDim.y - 1) / (int)gridDim.y, f_lo = (int)blockIdx.y * per, f_hi = min(f_lo + per, n_frames);
-    for (int f0 = f_lo + wave * TABLE_FRAMES; f0 < f_hi; f0 += 4 * TABLE_FRAMES) {
-        const int nf = min(TABLE_FRAMES, f_hi - f0);
+    for (int fw = f_lo + wave * PER_WAVE; fw < f_hi; fw += 4 * PER_WAVE) {
+        const int f0 = fw + part * TABLE_FRAMES;                 // this lane group's first frame
+        const int nf = max(0, min(TABLE_FRAMES, f_hi - f0));
         uint64_t s[TABLE_FRAMES][SUM_BB + 1];
 #pragma unroll
         for (int j = 0; j < TABLE_FRAMES; j++)
 #pragma unroll
             for (int k = 0; k <= SUM_BB; k++) s[j][k] = 0;
-        const float *__restrict__ t0 = t32c + (size_t)f0 * crop_px;
-        for (int g = lane; g < n; g += 64) {
-            const uint32_t off = goff[base + g];
-            const float4 d = gval[base + g];
-            float4 t[TABLE_FRAMES];
+        const float *__restrict__ t0 = t32c + (size_t)min(f0, n_frames - 1) * crop_px;
+        if (nf > 0)
+            for (int g = sub; g < n; g += LANES) {
+                const uint32_t off = goff[base + g];
+                const float4 d = gval[base + g];
+                float4 t[TABLE_FRAMES];
 #pragma unroll
-            for (int j = 0; j < TABLE_FRAMES; j++)
-                t[j] = j < nf ? *reinterpret_cast<const float4 *>(t0 + (size_t)j * crop_px + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int j = 0; j < TABLE_FRAMES; j++)
+                    t[j] = j < nf ? *reinterpret_cast<const float4 *>(t0 + (size_t)j * crop_px + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < TABLE_FRAMES; j++) table_group_delta(t[j], d, s[j]);
-        }
+                for (int j = 0; j < TABLE_FRAMES; j++) table_group_delta(t[j], d, s[j]);
+            }
 #pragma unroll
         for (int j = 0; j < TABLE_FRAMES; j++) {
-            if (j >= nf) break;
             uint64_t r[ROPE_SUM_WORDS];
 #pragma unroll
             for (int k = SUM_S1; k <= SUM_BB; k++) {
                 uint64_t v = s[j][k];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                for (int off = LANES / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // stays inside the lane group
                 r[k] = v;
             }
-            if (lane == 0) {
+            if (sub == 0 && j < nf) {
                 const uint64_t *total = totals + (size_t)(f0 + j) * ROPE_SUM_WORDS;
 #pragma unroll
                 for (int k = SUM_S1; k <= SUM_BB; k++) r[k] += total[k];
@@ -1977,16 +1982,21 @@ hipError_t launch_table_score_frames(hipStream_t st, const FrameParams &fp, cons
     hipLaunchKernelGGL(crop_total_kernel, dim3(n_frames), dim3(1024), 0, st, fp, t32, t32c, totals);
     // A workgroup takes 4 x F frames (F per wave), and the grid walks the table once per such chunk of frames (rows fastest): the
     // chunk's cropped targets stay in L2 while every row gathers from them, and the table streams past once per chunk.
-    // Measured for 256 frames x 15 625 rows at 160x90 (tools/r03_tbl_run.sh): F = 8 7.2 ms (221 registers, two waves per SIMD),
-    // F = 4 5.1 ms, F = 2 4.8 ms; one frame per wave and every frame in one workgroup (round 3's first form) 6.6 ms.
+    // Measured for 256 frames x 15 625 rows at 160x90 (tools/r03_tbl_run.sh), a whole wave per frame group: F = 8 7.2 ms (221
+    // registers, two waves per SIMD), F = 4 5.1 ms, F = 2 4.8-5.0 ms; one frame per wave and every frame in one workgroup (round 3's
+    // first form) 6.6 ms.  With F = 2 and the wave split into lane groups of 32 / 16 / 8: 4.0 / 3.4 / 3.2 ms.
     static const int F = [] { const char *e = std::getenv("ROPE_TABLE_FRAMES"); const int v = e ? std::atoi(e) : 2; return v == 4 || v == 8 ? v : 2; }();
-    const int chunks = std::max(1, (n_frames + 4 * F - 1) / (4 * F));
+    static const int LANES = [] { const char *e = std::getenv("ROPE_TABLE_LANES"); const int v = e ? std::atoi(e) : 16; return v == 64 || v == 8 ? v : 16; }();
+    const int per_wg = 4 * F * (64 / LANES);
+    const int chunks = std::max(1, (n_frames + per_wg - 1) / per_wg);
     const dim3 grid(C, chunks);
     const int words = (int)table_crop_words(fp);
     const double n_pix = (double)cw * (double)ch;
-    if (F == 2) hipLaunchKernelGGL(table_score_frames_kernel<2>, grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores);
-    else if (F == 4) hipLaunchKernelGGL(table_score_frames_kernel<4>, grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores);
-    else hipLaunchKernelGGL(table_score_frames_kernel<8>, grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores);
+#define ROPE_TABLE_LAUNCH(F_, L_) hipLaunchKernelGGL((table_score_frames_kernel<F_, L_>), grid, dim3(256), 0, st, words, counts, offs, goff, gval, t32c, totals, n_frames, n_pix, scores)
+    if (LANES == 16) { if (F == 2) ROPE_TABLE_LAUNCH(2, 16); else if (F == 4) ROPE_TABLE_LAUNCH(4, 16); else ROPE_TABLE_LAUNCH(8, 16); }
+    else if (LANES == 8) { if (F == 2) ROPE_TABLE_LAUNCH(2, 8); else ROPE_TABLE_LAUNCH(4, 8); }
+    else { if (F == 2) ROPE_TABLE_LAUNCH(2, 64); else if (F == 4) ROPE_TABLE_LAUNCH(4, 64); else ROPE_TABLE_LAUNCH(8, 64); }
+#undef ROPE_TABLE_LAUNCH
     hipLaunchKernelGGL(argmin_sets_kernel, dim3(n_frames), dim3(C <= 64 ? 64 : (C <= 256 ? 256 : 1024)), 0, st, scores, C, best);
     return hipGetLastError();
 }
